@@ -1,0 +1,137 @@
+/*
+ * sdmi.h -- C ABI of the MI355X-native Stable Diffusion denoising path (libsdmi.so).
+ *
+ * Plain C: pointers + sizes only, no torch/C++ types.  All *_dev pointers are HIP device pointers
+ * owned by the caller; `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call
+ * is asynchronous with respect to the host (stream-ordered) unless stated.  Return value: 0 on
+ * success, negative errno-style code otherwise (-22 EINVAL, -12 ENOMEM, -5 HIP failure, -2 missing
+ * tensor); sdmi_last_error() returns the thread-local message.  One handle per device; a handle is
+ * not thread-safe.
+ *
+ * The reference (dawmro/pytorch_stable_diffusion) has no FFI; the seam this ABI sits behind is its
+ * Python call surface:
+ *   models["diffusion"](latent, context, time)      sd/pipeline.py:225  -> sd/diffusion.py:797-837
+ *   the CFG combine + sampler.step of the loop      sd/pipeline.py:230-237 -> sd/ddpm.py:102-139
+ * and its weight ABI is the state-dict key set of sd/model_converter.py:13-650,1009-1024.
+ */
+#ifndef SDMI_H
+#define SDMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_F32 0
+#define SDMI_F16 1
+
+/* sdmi_unet_create flags */
+#define SDMI_FLAG_STREAM_F32 1 /* keep the residual stream in fp32 (fp16 shadow feeds the MFMA operands) */
+#define SDMI_FLAG_PARTIAL 2    /* allow a subset of the 654 tensors (block-level tests) */
+#define SDMI_FLAG_NO_TUNE 4    /* skip the per-shape tile/split-K autotune (heuristic configs) */
+
+typedef struct sdmi_unet sdmi_unet;
+
+/* One tensor of the reference's Diffusion state dict, in PyTorch layout on the device:
+ * conv weights OIHW, linear weights [out][in], fused self-attention in_proj rows ordered q|k|v
+ * (sd/model_converter.py:1009). */
+typedef struct sdmi_tensor_desc {
+  const char* name;
+  const void* data_dev;
+  int dtype; /* SDMI_F32 or SDMI_F16 */
+  int ndim;
+  int64_t shape[4];
+} sdmi_tensor_desc;
+
+const char* sdmi_last_error(void);
+int sdmi_version(void);
+
+/* Replaces Diffusion.__init__ + load_state_dict (sd/diffusion.py:797-812, sd/model_loader.py:38-42):
+ * packs the weights into fp16 kernel layouts ([N][kh][kw][Cin]); the library owns the packed copies
+ * and its activation arena.  Synchronous. */
+int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_unet** out);
+void sdmi_unet_destroy(sdmi_unet* u);
+
+/* Hoists the 32 loop-invariant cross-attention K/V projections of the context
+ * (sd/attention.py:221-222 via sd/diffusion.py:338).  ctx_dev: (batch, n_tokens, 768) fp32. */
+int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_tokens, void* stream);
+
+/* Precomputes TimeEmbedding (sd/diffusion.py:64-76) and the 22 per-ResBlock SiLU->linear_time
+ * vectors (sd/diffusion.py:184-187) for every step of a schedule.
+ * temb_dev: (n_steps, 320) fp32 = get_time_embedding(t) rows (sd/pipeline.py:310-349). */
+int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, void* stream);
+
+/* Replaces Diffusion.forward (sd/diffusion.py:797-837) on NCHW fp32 I/O like the reference.
+ * latents_dev: (latent_batch, 4, h, w) fp32; latent_batch == 1 with batch == 2 implements the CFG
+ * `repeat(2,1,1,1)` (sd/pipeline.py:221) without a copy.  Time input: temb_dev != NULL -> (1,320)
+ * fp32 embedding used directly; else row step_idx of the schedule.  eps_out_dev: (batch,4,h,w) fp32. */
+int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev,
+                      int step_idx, float* eps_out_dev, int batch, int h, int w, void* stream);
+
+/* Replaces the CFG combine (sd/pipeline.py:230-233) + DDPMSampler.step (sd/ddpm.py:102-139), fused.
+ * eps_dev: (2,4,h,w) if do_cfg else (1,4,h,w); latents_dev updated in place; noise_dev: N(0,1) draw
+ * or NULL when t == 0; coef = {sqrt(1-abar_t), sqrt(abar_t), pred_original_sample_coeff,
+ * current_sample_coeff, sqrt(variance)} evaluated by the host in the reference's fp32 order;
+ * n = 4*h*w elements.  eps_out_dev (optional) receives the guided eps. */
+int sdmi_cfg_ddpm_step(const float* eps_dev, int do_cfg, float cfg_scale, float* latents_dev,
+                       const float* noise_dev, const float* coef, int64_t n, float* eps_out_dev, void* stream);
+
+/* One whole denoising step = sdmi_unet_forward(step_idx) + sdmi_cfg_ddpm_step on the handle's own
+ * eps buffer (the loop body of sd/pipeline.py:208-237). */
+int sdmi_unet_denoise_step(sdmi_unet* u, float* latents_dev, int step_idx, int do_cfg, float cfg_scale,
+                           const float* noise_dev, const float* coef, int h, int w, void* stream);
+
+/* Block-level entry points (parity tests): run ONE reference sub-module on NHWC fp32 device tensors.
+ * kind: 0 = UNET_ResidualBlock (sd/diffusion.py:145-209; time_dev = (1,1280) TimeEmbedding output),
+ *       1 = UNET_AttentionBlock (sd/diffusion.py:271-381; uses the context set by set_context),
+ *       2 = Upsample (sd/diffusion.py:412-435), 3 = 3x3 conv stride `arg`, 4 = UNET_OutputLayer
+ *       (out is NCHW fp32 (B,4,H,W)).  x1_dev/c1: optional second concat source for kind 0. */
+int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, const float* x0_dev, int c0,
+                        const float* x1_dev, int c1, int batch, int h, int w, const float* time_dev,
+                        float* out_dev, void* stream);
+
+/* Number of kernel launches enqueued by the last sdmi_unet_forward, and bytes of packed weights. */
+int sdmi_unet_last_launch_count(const sdmi_unet* u);
+int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);
+
+/* ---- kernel-level entry points (parity tests / micro-benchmarks) ------------------------------ */
+
+/* Implicit-GEMM conv / linear:  out[m][n] = sum_k A(m,k) w[n][k] + bias[n] + res[m][n].
+ * a0/a1: NHWC fp16 sources (virtual channel concat), w: packed [N][ks*ks*(c0+c1)] fp16 with k ordered
+ * (kh,kw,ci).  cfg < 0: heuristic tile; ksplit >= 1.  out_t (optional): columns >= nt0 written
+ * transposed as out_t[(b*(N-nt0)+n-nt0)*ldt + s] with m = b*S + s. */
+typedef struct sdmi_gemm_desc {
+  const void* a0; const void* a1;
+  int c0, c1, hs, ws, ho, wo, ups, stride, pad, ks;
+  int M, N, K;
+  const void* w;
+  const float* bias;
+  const void* res; int res_f32; int ldr;
+  void* out; int out_f32; int ldc;
+  void* out16;
+  void* out_t; int nt0; int S; int ldt;
+  int cfg; int ksplit;
+} sdmi_gemm_desc;
+int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
+int sdmi_gemm_num_configs(void);
+const char* sdmi_gemm_config_name(int cfg);
+
+/* PyTorch OIHW (fp32/fp16) -> packed [o < o_keep][kh][kw][I] fp16. */
+int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream);
+
+/* Flash attention: q [B*Sq][ldq], k [B*k_batch_stride][ldk], vt [(b*H+h)*d+dd][ldvt] (keys
+ * contiguous, zero-padded to a multiple of 64), o [B*Sq][ldo]; all fp16. */
+int sdmi_op_attention(const void* q, int ldq, const void* k, int ldk, int k_batch_stride, const void* vt, int ldvt,
+                      void* o, int ldo, int B, int H, int d, int Sq, int Skv, void* stream);
+
+/* GroupNorm(32) over NHWC (optionally two concat sources), fp16 out; LayerNorm over rows. */
+int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P,
+                      const float* gamma, const float* beta, float eps, int silu, void* y_f16, void* stream);
+int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,
+                      void* y_f16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H */

@@ -1,0 +1,226 @@
+"""ctypes binding of libsdmi.so (include/sdmi.h).  PyTorch supplies device memory and the current
+stream only; every kernel on the hot path lives in the library.  There is NO fallback: if the
+library cannot be loaded the import error propagates."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import build as _build
+
+SDMI_F32, SDMI_F16 = 0, 1
+FLAG_STREAM_F32, FLAG_PARTIAL, FLAG_NO_TUNE = 1, 2, 4
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data_dev", C.c_void_p), ("dtype", C.c_int), ("ndim", C.c_int),
+                ("shape", C.c_int64 * 4)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("a0", C.c_void_p), ("a1", C.c_void_p),
+                ("c0", C.c_int), ("c1", C.c_int), ("hs", C.c_int), ("ws", C.c_int), ("ho", C.c_int),
+                ("wo", C.c_int), ("ups", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("ks", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("res", C.c_void_p), ("res_f32", C.c_int), ("ldr", C.c_int),
+                ("out", C.c_void_p), ("out_f32", C.c_int), ("ldc", C.c_int),
+                ("out16", C.c_void_p),
+                ("out_t", C.c_void_p), ("nt0", C.c_int), ("S", C.c_int), ("ldt", C.c_int),
+                ("cfg", C.c_int), ("ksplit", C.c_int)]
+
+
+_LIB: Optional[C.CDLL] = None
+
+_SIGNATURES = {
+    "sdmi_last_error": (C.c_char_p, []),
+    "sdmi_version": (C.c_int, []),
+    "sdmi_unet_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdmi_unet_destroy": (None, [C.c_void_p]),
+    "sdmi_unet_set_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_unet_set_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sdmi_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_cfg_ddpm_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
+                                     C.c_int64, C.c_void_p, C.c_void_p]),
+    "sdmi_unet_denoise_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                         C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_unet_run_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdmi_unet_last_launch_count": (C.c_int, [C.c_void_p]),
+    "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
+    "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sdmi_gemm_num_configs": (C.c_int, []),
+    "sdmi_gemm_config_name": (C.c_char_p, [C.c_int]),
+    "sdmi_op_pack_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_op_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "sdmi_op_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                    C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load libsdmi.so (building it with hipcc first when it is absent/stale and hipcc exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_native(verbose=False)
+        except Exception as exc:  # no toolchain on this box and no prebuilt library
+            if not os.path.exists(path):
+                raise ImportError(f"libsdmi.so is not built and could not be built: {exc}") from exc
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+class SdmiError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = load().sdmi_last_error().decode("utf-8", "replace")
+    if rc == -22:
+        raise ValueError(f"{what}: {msg}")
+    if rc == -2:
+        raise KeyError(f"{what}: {msg}")
+    raise SdmiError(f"{what}: rc={rc}: {msg}")
+
+
+def cur_stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return SDMI_F32
+    if t.dtype == torch.float16:
+        return SDMI_F16
+    raise TypeError(f"unsupported weight dtype {t.dtype} (need float32 or float16)")
+
+
+class UNetHandle:
+    """Owns one native sdmi_unet.  ``state`` maps the reference's state-dict keys to CUDA tensors."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], flags: int = 0):
+        lib = load()
+        if not state:
+            raise ValueError("empty state dict")
+        descs = (TensorDesc * len(state))()
+        keep = []
+        for i, (k, v) in enumerate(state.items()):
+            if not v.is_cuda:
+                raise ValueError(f"weight '{k}' is not on the GPU")
+            v = v.contiguous()
+            keep.append(v)
+            kb = k.encode()
+            keep.append(kb)
+            descs[i].name = kb
+            descs[i].data_dev = v.data_ptr()
+            descs[i].dtype = _dtype_code(v)
+            descs[i].ndim = v.dim()
+            for j, s in enumerate(v.shape):
+                descs[i].shape[j] = s
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(lib.sdmi_unet_create(descs, len(state), flags, C.byref(h)), "sdmi_unet_create")
+        self._h = h
+        self._lib = lib
+        self.flags = flags
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdmi_unet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_context(self, ctx: torch.Tensor):
+        assert ctx.is_cuda and ctx.dtype == torch.float32 and ctx.dim() == 3 and ctx.shape[2] == 768
+        ctx = ctx.contiguous()
+        check(self._lib.sdmi_unet_set_context(self._h, ptr(ctx), ctx.shape[0], ctx.shape[1], cur_stream()),
+              "sdmi_unet_set_context")
+
+    def set_schedule(self, temb: torch.Tensor):
+        assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.shape[1] == 320
+        temb = temb.contiguous()
+        check(self._lib.sdmi_unet_set_schedule(self._h, ptr(temb), temb.shape[0], cur_stream()),
+              "sdmi_unet_set_schedule")
+
+    def forward(self, latents: torch.Tensor, batch: int, temb: Optional[torch.Tensor] = None,
+                step_idx: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.dim() == 4 and latents.shape[1] == 4
+        latents = latents.contiguous()
+        lb, _, h, w = latents.shape
+        if out is None:
+            out = torch.empty((batch, 4, h, w), dtype=torch.float32, device=latents.device)
+        if temb is not None:
+            assert temb.is_cuda and temb.dtype == torch.float32 and temb.numel() == 320
+            temb = temb.contiguous()
+        check(self._lib.sdmi_unet_forward(self._h, ptr(latents), lb, ptr(temb), step_idx, ptr(out), batch, h, w,
+                                          cur_stream()), "sdmi_unet_forward")
+        return out
+
+    def denoise_step(self, latents: torch.Tensor, step_idx: int, do_cfg: bool, cfg_scale: float,
+                     noise: Optional[torch.Tensor], coef):
+        _, _, h, w = latents.shape
+        c = (C.c_float * 5)(*[float(x) for x in coef])
+        check(self._lib.sdmi_unet_denoise_step(self._h, ptr(latents), step_idx, int(do_cfg), float(cfg_scale),
+                                               ptr(noise), c, h, w, cur_stream()), "sdmi_unet_denoise_step")
+
+    def run_block(self, prefix: str, kind: int, x0: torch.Tensor, x1: Optional[torch.Tensor] = None,
+                  time: Optional[torch.Tensor] = None, arg: int = 1, out_shape=None) -> torch.Tensor:
+        """x0/x1: NHWC fp32 CUDA tensors (B,H,W,C).  Returns NHWC fp32 (kind 4: NCHW (B,4,H,W))."""
+        B, H, W, c0 = x0.shape
+        c1 = 0 if x1 is None else x1.shape[3]
+        out = torch.empty(out_shape, dtype=torch.float32, device=x0.device)
+        check(self._lib.sdmi_unet_run_block(self._h, prefix.encode(), kind, arg, ptr(x0.contiguous()), c0,
+                                            ptr(None if x1 is None else x1.contiguous()), c1, B, H, W,
+                                            ptr(time), ptr(out), cur_stream()), "sdmi_unet_run_block")
+        return out
+
+    @property
+    def last_launch_count(self) -> int:
+        return self._lib.sdmi_unet_last_launch_count(self._h)
+
+    @property
+    def weight_bytes(self) -> int:
+        return self._lib.sdmi_unet_weight_bytes(self._h)
+
+
+def cfg_ddpm_step(eps, do_cfg, cfg_scale, latents, noise, coef, eps_out=None):
+    lib = load()
+    c = (C.c_float * 5)(*[float(x) for x in coef])
+    n = latents.numel()
+    check(lib.sdmi_cfg_ddpm_step(ptr(eps), int(do_cfg), float(cfg_scale), ptr(latents), ptr(noise), c, n,
+                                 ptr(eps_out), cur_stream()), "sdmi_cfg_ddpm_step")

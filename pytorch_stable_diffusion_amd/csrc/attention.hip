@@ -1,0 +1,251 @@
+// Flash-style multi-head attention for gfx950 (MI355X): softmax(Q K^T / sqrt(d)) V without
+// materialising the S x S scores.  Replaces the materialised-score attention of the reference
+// (sd/attention.py:55-86 self-attention, :219-244 cross-attention) for the UNet's head sizes
+// d in {40, 80, 160} (8 heads; sd/diffusion.py:543-626).
+//
+// Design (one workgroup = 4 waves = 128 queries of one (batch, head); 64-key K/V tiles):
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_f16: the query index lands on the LANE and the key index
+//     in the accumulator registers, so the online-softmax row max/sum is register-local plus one
+//     lane^32 exchange, and the exponentiated tile P^T is ALREADY laid out as the B operand of the
+//     next product (accumulator-as-operand; no LDS round trip for P).
+//   * O^T += V^T P^T: V arrives pre-transposed ([b][h*d+dd][key], written by the projection GEMM's
+//     transposed epilogue), so both K and V^T tiles are plain row gathers staged by LDS-DMA.
+//   * K tile rows are d*2 bytes (80-byte stride is bank-conflict-free for d=40, the S=4096 case that
+//     carries 88% of attention FLOPs); V^T tile rows are 128 B with the GEMM's XOR swizzle.
+//   * the head-dim contraction is zero-padded on the Q fragment only (d=40 -> 48).
+//   * keys >= Skv are masked (cross-attention: 77 keys in a 128-key double tile).
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int D>
+struct ACfg {
+  static constexpr int NS = (D + 15) / 16;          // k16 steps of the QK^T contraction
+  static constexpr int DP = ((D + 31) / 32) * 32;   // padded head dim (rows of V^T tile)
+  static constexpr int DB = DP / 32;
+  static constexpr int KCH = D / 8;                 // 16-B chunks per K row
+  static constexpr int K_BYTES = 64 * D * 2;
+  static constexpr int K_INST = (64 * KCH) / 64;    // = KCH wave-instructions per tile
+  static constexpr int V_BYTES = DP * 128;
+  static constexpr int V_INST = DP / 8;
+  static constexpr int STAGE = K_BYTES + V_BYTES;
+  static constexpr int LDS = 2 * STAGE;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+  typedef ACfg<D> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / p.H, head = bh % p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ntiles = (p.Skv + 63) >> 6;
+
+  const f16* kbase = p.k + (size_t)b * p.k_batch_stride * p.ldk + head * D;
+  const f16* vbase = p.vt + ((size_t)(b * p.H + head) * D) * p.ldvt;
+
+  auto stage = [&](int tile, int buf) {
+    char* sk = smem + buf * C::STAGE;
+    char* sv = sk + C::K_BYTES;
+    const int key0 = tile * 64;
+#pragma unroll
+    for (int i = 0; i < (C::K_INST + 3) / 4; ++i) {
+      const int ii = i * 4 + wave;
+      if (ii < C::K_INST) {
+        const int q = ii * 64 + lane;
+        const int row = q / C::KCH, c = q - row * C::KCH;
+        const int key = key0 + row;
+        const f16* g = key < p.Skv ? kbase + (size_t)key * p.ldk + c * 8 : p.zero + (c & 7) * 8;
+        glds16(g, sk + ii * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::V_INST / 4; ++i) {
+      const int ii = i * 4 + wave;
+      const int q = ii * 64 + lane;
+      const int row = q >> 3, pc = q & 7;
+      const int gch = pc ^ ((row >> 1) & 7);
+      const f16* g = row < D ? vbase + (size_t)row * p.ldvt + key0 + gch * 8 : p.zero + gch * 8;
+      glds16(g, sv + ii * 1024);
+    }
+  };
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q = r, half h) holds dk = 16 s + 8 h + j ----
+  f16x8 qf[C::NS];
+  {
+    int qi = q0 + r;
+    if (qi >= p.Sq) qi = p.Sq - 1;
+    const f16* qp = p.q + ((size_t)b * p.Sq + qi) * p.ldq + head * D;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+      const int dk = 16 * s + 8 * h;
+      if (dk < D) {
+        qf[s] = *(const f16x8*)(qp + dk);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (f16)0.f;
+      }
+    }
+  }
+
+  // K fragment byte offsets within a K tile row (clamped to the row start where Q is zero-padded)
+  int koff[C::NS];
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    const int dk = 16 * s + 8 * h;
+    koff[s] = dk < D ? dk * 2 : 0;
+  }
+  const int vkey = (r >> 1) & 7;
+
+  f32x16 oacc[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.4426950408889634f;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+    const char* Ks = smem + cur * C::STAGE;
+    const char* Vs = Ks + C::K_BYTES;
+
+    // ---- S^T tile: 64 keys x 32 queries ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) {
+        const f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r) * (D * 2) + koff[s]);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // mask keys beyond Skv (only possible in the last tile)
+    if (t == ntiles - 1 && (p.Skv & 63) != 0) {
+      const int kbase_i = t * 64 + 4 * h;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase_i + kb * 32 + (e & 3) + 8 * (e >> 2);
+          if (key >= p.Skv) sacc[kb][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (per query = per lane; the two half-waves hold disjoint keys) ----
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(sacc[kb][e] * c - mc);
+        sacc[kb][e] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)sacc[kb][8 * s2 + e];
+        const int ch0 = 4 * kb + 2 * s2;
+        const int o0 = ((ch0 ^ vkey) << 4) + 8 * h;
+        const int o1 = (((ch0 + 1) ^ vkey) << 4) + 8 * h;
+#pragma unroll
+        for (int d = 0; d < C::DB; ++d) {
+          const char* vrow = Vs + (d * 32 + r) * 128;
+          const f16x4 lo = *(const f16x4*)(vrow + o0);
+          const f16x4 hi = *(const f16x4*)(vrow + o1);
+          f16x8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- normalise and store: lane = query row, registers = head-dim ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qi = q0 + r;
+  if (qi < p.Sq) {
+    f16* op = p.o + ((size_t)b * p.Sq + qi) * p.ldo + head * D;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * h;
+        if (dd < D) {
+          f16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (f16)(oacc[d][4 * g + e] * inv);
+          *(f16x4*)(op + dd) = o4;
+        }
+      }
+  }
+}
+
+template <int D>
+int launch(const AttnArgs& a, hipStream_t st) {
+  typedef ACfg<D> C;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    attr_done = true;
+  }
+  dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+  hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), C::LDS, st, a);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+}  // namespace
+
+int sdmi_launch_attention(const AttnArgs& a, hipStream_t st) {
+  SDMI_REQUIRE(a.q && a.k && a.vt && a.o && a.zero, "attention: null pointer");
+  SDMI_REQUIRE(a.Sq > 0 && a.Skv > 0 && a.B > 0 && a.H > 0, "attention: bad sizes");
+  SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be 16-B aligned");
+  SDMI_REQUIRE(a.ldvt >= ((a.Skv + 63) / 64) * 64, "attention: V^T rows must be padded to a multiple of 64 keys (ldvt=%d, Skv=%d)", a.ldvt, a.Skv);
+  switch (a.d) {
+    case 40: return launch<40>(a, st);
+    case 80: return launch<80>(a, st);
+    case 160: return launch<160>(a, st);
+    case 64: return launch<64>(a, st);
+    default: sdmi_set_error("attention: unsupported head dim %d", a.d); return SDMI_EINVAL;
+  }
+}

@@ -1,0 +1,141 @@
+// Common device/host declarations for the sdmi (Stable Diffusion on MI355X) native library.
+// gfx950 / CDNA4 only: 64-wide wavefronts, MFMA 32x32x16 f16, LDS-DMA (global_load_lds).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SDMI_OK 0
+#define SDMI_EINVAL (-22)
+#define SDMI_ENOMEM (-12)
+#define SDMI_EHIP (-5)
+#define SDMI_ENOENT (-2)
+
+// Thread-local error message (sdmi_last_error).
+void sdmi_set_error(const char* fmt, ...);
+
+#define SDMI_CHECK_HIP(expr)                                                         \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      sdmi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return SDMI_EHIP;                                                              \
+    }                                                                                \
+  } while (0)
+
+#define SDMI_REQUIRE(cond, ...)                   \
+  do {                                            \
+    if (!(cond)) {                                \
+      sdmi_set_error(__VA_ARGS__);                \
+      return SDMI_EINVAL;                         \
+    }                                             \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor:  D[m][n] = sum_k A(m,k) * W[n][k]
+//   A(m,k) is gathered on the fly from one or two NHWC fp16 tensors (virtual channel concat),
+//   optional nearest x2 upsample, ks x ks taps with stride/pad (ks = 1 -> plain GEMM).
+//   k is ordered (kh, kw, ci); W is packed [N][K] fp16 with K contiguous.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const f16* a0;
+  const f16* a1;       // second concat source or nullptr
+  int C0, C1;          // channels per source (C1 = 0 when a1 == nullptr); multiples of 64
+  int Hs, Ws;          // stored source spatial dims
+  int Ho, Wo;          // output spatial dims; M = B*Ho*Wo
+  int ups;             // 1: nearest x2 upsample applied to the source on read
+  int stride, pad, ks;
+  int M, N, K;         // K = ks*ks*(C0+C1), multiple of 64; N multiple of 8
+  const f16* w;        // [N][K]
+  const f16* zero;     // >= 256 B of zeros (source for padded taps / out-of-range rows)
+  // epilogue:  out = D + bias[n] + res[m][n]
+  const float* bias;   // [N] or nullptr
+  const void* res;     // [M][ldr] fp16 or fp32, or nullptr
+  int res_f32;
+  int ldr;
+  void* out;           // [M][ldc] fp16 or fp32
+  int out_f32;
+  int ldc;
+  f16* out16;          // optional fp16 shadow copy [M][ldc] (used when out_f32)
+  // columns n >= nt0 are written transposed: outT[(b*(N-nt0) + n-nt0)*ldt + s],  m = b*S + s
+  f16* outT;
+  int nt0;
+  int S;
+  int ldt;
+  // split-K: partial sums to slab[z][M][N] (fp32), combined by splitk_finalize
+  float* slab;
+  int ksplit;
+  int ksteps_per;
+};
+
+int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
+int sdmi_gemm_num_cfgs();
+const char* sdmi_gemm_cfg_name(int cfg);
+size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int cfg, int ksplit);
+
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const f16* q; int ldq;     // [B*Sq][ldq], head h at columns h*d
+  const f16* k; int ldk;     // [B*Skv_stored][ldk]
+  const f16* vt; int ldvt;   // V transposed: [(b*H*d + h*d + dd)][ldvt] (keys contiguous)
+  f16* o; int ldo;           // [B*Sq][ldo]
+  int B, H, d;               // d in {40, 80, 160} (multiple of 8, <= 160)
+  int Sq, Skv;               // Skv = number of valid keys (masking beyond)
+  int k_batch_stride;        // rows of k per batch (>= Skv)
+  const f16* zero;
+  float scale;               // 1/sqrt(d)
+};
+int sdmi_launch_attention(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Norms over NHWC activations (stream dtype fp16 or fp32), fp16 normalised output.
+struct GnArgs {
+  const void* x0; const void* x1;   // concat sources (x1 may be null)
+  int in_f32;
+  int C0, C1;
+  int B, P;                          // P = H*W pixels
+  const float* gamma; const float* beta;   // [C]
+  float eps;
+  int silu;
+  f16* y;                            // [B*P][C0+C1]
+  float* partial;                    // scratch: [B][nchunk][32][2]
+  int nchunk;
+};
+int sdmi_gn_nchunk(int P);
+int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st);
+
+struct LnArgs {
+  const void* x; int in_f32;  // [M][C]
+  int M, C;
+  const float* gamma; const float* beta;
+  float eps;
+  f16* y;
+};
+int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st);
+
+// misc kernels (misc.hip)
+int sdmi_launch_cast_f32_f16(const float* x, f16* y, size_t n, hipStream_t st);
+int sdmi_launch_pack_conv(const void* w, int w_f32, f16* out, int O, int I, int ks, int o_keep, hipStream_t st);
+int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, hipStream_t st);
+int sdmi_launch_cast_any_f32(const void* x, int in_f32, float* y, size_t n, hipStream_t st);
+// y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n]   (fp32 x/y, fp16 W), act = SiLU if silu
+int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float* y, int M, int N, int K,
+                             int silu, int ldy, hipStream_t st);
+// stem conv 4->Cout from NCHW fp32 latents (batch-broadcast when lat_batch == 1)
+int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias,
+                          void* out, int out_f32, f16* out16, int B, int H, int W, int Cout, hipStream_t st);
+// final conv Cin->4 from NHWC fp16 (already GN+SiLU) to NCHW fp32
+int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W,
+                           int Cin, hipStream_t st);
+int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,
+                         const float* coef, size_t n, float* eps_out, hipStream_t st);
+int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st);
+int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);

@@ -1,0 +1,296 @@
+// Small kernels around the GEMM/attention core (gfx950):
+//   weight packing, casts, the timestep-embedding GEMV chain, the 4->320 stem conv that reads NCHW
+//   fp32 latents directly, the 320->4 output conv that writes NCHW fp32, and the fused
+//   classifier-free-guidance combine + DDPM ancestral step.
+#include "common.h"
+
+namespace {
+
+__global__ void cast_f32_f16_kernel(const float* x, f16* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = (f16)x[i];
+}
+
+__global__ void cast_any_f32_kernel(const void* x, int in_f32, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = in_f32 ? ((const float*)x)[i] : (float)((const f16*)x)[i];
+}
+
+// PyTorch conv weight [O][I][ks][ks] -> packed [o < o_keep][kh][kw][I] fp16 (K ordered (kh,kw,ci)).
+// Linear weights are the ks = 1 case.  (reference weight ABI: sd/model_converter.py:13-650)
+__global__ void pack_conv_kernel(const void* w, int w_f32, f16* out, int O, int I, int ks, int o_keep) {
+  const size_t total = (size_t)o_keep * ks * ks * I;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(idx % I);
+    size_t t = idx / I;
+    const int kw = (int)(t % ks);
+    t /= ks;
+    const int kh = (int)(t % ks);
+    const int o = (int)(t / ks);
+    const size_t src = (((size_t)o * I + ci) * ks + kh) * ks + kw;
+    out[idx] = w_f32 ? (f16)((const float*)w)[src] : ((const f16*)w)[src];
+  }
+}
+
+// y[m][n] = sum_k act(x[m][k]) W[n][k] + b[n];  one wave per n, W row kept in registers, loop m.
+// Timestep path: sd/diffusion.py:64-76 (TimeEmbedding) and :184-187 (SiLU -> linear_time).
+template <int NCH>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const f16* w, const float* b, float* y,
+                                                           int M, int N, int K, int silu, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int K8 = K / 8;
+  float wv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = lane + i * 64;
+    if (c8 < K8) {
+      const f16x8 t = *(const f16x8*)(w + (size_t)n * K + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[i][e] = (float)t[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[i][e] = 0.f;
+    }
+  }
+  const float bias = b ? b[n] : 0.f;
+  for (int m = 0; m < M; ++m) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + i * 64;
+      if (c8 < K8) {
+        const float* xp = x + (size_t)m * K + c8 * 8;
+        const f32x4 a0 = *(const f32x4*)xp, a1 = *(const f32x4*)(xp + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = e < 4 ? a0[e] : a1[e - 4];
+          if (silu) v = v / (1.f + expf(-v));
+          acc += v * wv[i][e];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[(size_t)m * ldy + n] = acc + bias;
+  }
+}
+
+// Stem conv 4 -> Cout, 3x3 s1 p1 (sd/diffusion.py:545), input NCHW fp32 latents (batch-broadcast
+// implements latents.repeat(2,1,1,1) of sd/pipeline.py:221 without a copy), output NHWC.
+// w36: [36][Cout] fp32 with k = (kh*3+kw)*4 + ci.   thread = (pixel, 8 output channels)
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int lat_batch, const float* w36,
+                                                        const float* bias, void* out, int out_f32, f16* out16,
+                                                        int B, int H, int W, int Cout) {
+  const int C8 = Cout / 8;
+  const size_t total = (size_t)B * H * W * C8;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    const size_t pix = idx / C8;
+    const int ow = (int)(pix % W);
+    const int oh = (int)((pix / W) % H);
+    const int b = (int)(pix / ((size_t)W * H));
+    const int lb = lat_batch == 1 ? 0 : b;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias[c8 * 8 + e];
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh + kh - 1;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow + kw - 1;
+        if ((unsigned)iw >= (unsigned)W) continue;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const float xv = lat[(((size_t)lb * 4 + ci) * H + ih) * W + iw];
+          const float* wp = w36 + (size_t)((kh * 3 + kw) * 4 + ci) * Cout + c8 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += xv * wp[e];
+        }
+      }
+    }
+    f16x8 o16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o16[e] = (f16)acc[e];
+    const size_t off = pix * Cout + c8 * 8;
+    if (out_f32) {
+      float* op = (float*)out + off;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) op[e] = acc[e];
+      if (out16) *(f16x8*)(out16 + off) = o16;
+    } else {
+      *(f16x8*)((f16*)out + off) = o16;
+    }
+  }
+}
+
+__global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout) {
+  const int total = 36 * Cout;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int co = idx % Cout, k = idx / Cout;
+    const int ci = k % 4, tap = k / 4, kh = tap / 3, kw = tap % 3;
+    const size_t src = (((size_t)co * 4 + ci) * 3 + kh) * 3 + kw;
+    w36[idx] = w_f32 ? ((const float*)w)[src] : (float)((const f16*)w)[src];
+  }
+}
+
+// Output conv Cin -> 4, 3x3 s1 p1 (sd/diffusion.py:744) on the GN+SiLU'd NHWC fp16 tensor,
+// result NCHW fp32 (B,4,H,W).  One wave per output pixel; w packed [4][3][3][Cin] fp16.
+__global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16* w, const float* bias, float* out,
+                                                         int B, int H, int W, int Cin) {
+  const int lane = threadIdx.x & 63;
+  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t npix = (size_t)B * H * W;
+  if (pix >= npix) return;
+  const int ow = (int)(pix % W);
+  const int oh = (int)((pix / W) % H);
+  const int b = (int)(pix / ((size_t)W * H));
+  const int C8 = Cin / 8;
+  const int items = 9 * C8;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int it = lane; it < items; it += 64) {
+    const int tap = it / C8, c8 = it - tap * C8;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int ih = oh + kh - 1, iw = ow + kw - 1;
+    if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+    const f16x8 xv = *(const f16x8*)(x + (((size_t)b * H + ih) * W + iw) * Cin + c8 * 8);
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[co] += (float)xv[e] * (float)wv[e];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
+  if (lane == 0) {
+#pragma unroll
+    for (int co = 0; co < 4; ++co) out[(((size_t)b * 4 + co) * H + oh) * W + ow] = acc[co] + bias[co];
+  }
+}
+
+struct DdpmCoef { float sqrt_beta_prod, sqrt_alpha_prod, c0, ct, sigma; int has_noise; };
+
+// CFG combine (sd/pipeline.py:230-233, cond first) + ancestral DDPM step (sd/ddpm.py:116-137).
+// Operation order and rounding follow the reference's fp32 tensor expression exactly (no FMA
+// contraction), so with identical eps the result is bit-identical to the reference step.
+__global__ __launch_bounds__(256) void cfg_ddpm_kernel(const float* eps, int do_cfg, float cfg_scale, float* latents,
+                                                       const float* noise, DdpmCoef k, size_t n, float* eps_out) {
+#pragma clang fp contract(off)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float e = eps[i];
+    if (do_cfg) {
+      const float eu = eps[n + i];
+      const float d = e - eu;
+      const float sd = cfg_scale * d;
+      e = sd + eu;
+    }
+    if (eps_out) eps_out[i] = e;
+    const float x = latents[i];
+    const float t1 = k.sqrt_beta_prod * e;
+    const float t2 = x - t1;
+    const float x0 = t2 / k.sqrt_alpha_prod;
+    const float a = k.c0 * x0;
+    const float bb = k.ct * x;
+    float prev = a + bb;
+    if (k.has_noise) {
+      const float v = k.sigma * noise[i];
+      prev = prev + v;
+    }
+    latents[i] = prev;
+  }
+}
+
+__global__ void add_vec_kernel(const float* a, const float* b, float* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+
+inline int nblocks(size_t n, int per = 256, int cap = 4096) {
+  size_t b = (n + per - 1) / per;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+int sdmi_launch_cast_f32_f16(const float* x, f16* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, y, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_cast_any_f32(const void* x, int in_f32, float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(cast_any_f32_kernel, dim3(nblocks(n)), dim3(256), 0, st, x, in_f32, y, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_pack_conv(const void* w, int w_f32, f16* out, int O, int I, int ks, int o_keep, hipStream_t st) {
+  const size_t total = (size_t)o_keep * ks * ks * I;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(nblocks(total)), dim3(256), 0, st, w, w_f32, out, O, I, ks, o_keep);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_kernel, dim3(nblocks(36 * (size_t)Cout)), dim3(256), 0, st, w, w_f32, w36, Cout);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float* y, int M, int N, int K,
+                             int silu, int ldy, hipStream_t st) {
+  SDMI_REQUIRE(K % 8 == 0 && K <= 8 * 64 * 3, "small_linear: K=%d unsupported", K);
+  const int nch = (K / 8 + 63) / 64;
+  dim3 grid((N + 3) / 4), block(256);
+  if (nch == 1) hipLaunchKernelGGL(small_linear_kernel<1>, grid, block, 0, st, x, w, b, y, M, N, K, silu, ldy);
+  else if (nch == 2) hipLaunchKernelGGL(small_linear_kernel<2>, grid, block, 0, st, x, w, b, y, M, N, K, silu, ldy);
+  else hipLaunchKernelGGL(small_linear_kernel<3>, grid, block, 0, st, x, w, b, y, M, N, K, silu, ldy);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias, void* out,
+                          int out_f32, f16* out16, int B, int H, int W, int Cout, hipStream_t st) {
+  SDMI_REQUIRE(Cout % 8 == 0, "stem conv: Cout=%d", Cout);
+  const size_t total = (size_t)B * H * W * (Cout / 8);
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(nblocks(total)), dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32,
+                     out16, B, H, W, Cout);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W, int Cin,
+                           hipStream_t st) {
+  SDMI_REQUIRE(Cin % 8 == 0, "final conv: Cin=%d", Cin);
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,
+                         const float* coef, size_t n, float* eps_out, hipStream_t st) {
+  DdpmCoef k;
+  k.sqrt_beta_prod = coef[0];
+  k.sqrt_alpha_prod = coef[1];
+  k.c0 = coef[2];
+  k.ct = coef[3];
+  k.sigma = coef[4];
+  k.has_noise = noise != nullptr;
+  hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(nblocks(n, 256, 1024)), dim3(256), 0, st, eps, do_cfg, cfg_scale, latents,
+                     noise, k, n, eps_out);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(add_vec_kernel, dim3(nblocks(n)), dim3(256), 0, st, a, b, y, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}

@@ -1,0 +1,208 @@
+// GroupNorm(32) and LayerNorm over NHWC (token-major) activations for gfx950.
+//
+// GroupNorm (reference call sites sd/diffusion.py:173,199,294,733): two launches,
+//   gn_stats : per (image, pixel-chunk) partial {sum, sum of squares} per group, fp32, from one or
+//              two concat sources (the skip concat of sd/diffusion.py:671 is never materialised);
+//   gn_apply : reduces the partials, y = (x - mean) * rstd * gamma + beta, optional SiLU, fp16 out
+//              (this is the A operand of the following conv / 1x1 conv).
+// LayerNorm (sd/diffusion.py:317,334,351): one wave per token row, exact two-pass statistics held
+// in registers, fp16 out.  Statistics are fp32; biased variance like torch.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void load8(const void* base, int is_f32, size_t elem_off, float (&v)[8]) {
+  if (is_f32) {
+    const f32x4 a = *(const f32x4*)((const float*)base + elem_off);
+    const f32x4 b = *(const f32x4*)((const float*)base + elem_off + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  } else {
+    const f16x8 a = *(const f16x8*)((const f16*)base + elem_off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+  }
+}
+
+// grid: (nchunk, B); block: (C/8) * PY threads (<= 320), thread = (channel chunk c8, pixel lane py)
+__global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix_per_chunk) {
+  __shared__ float s_sum[32], s_sq[32];
+  const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
+  const int tid = threadIdx.x;
+  const int c8 = tid % C8, py = tid / C8;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  if (tid < 32) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+  __syncthreads();
+  const int c = c8 * 8;
+  const bool second = c >= p.C0;
+  const void* base = second ? p.x1 : p.x0;
+  const int cs = second ? p.C1 : p.C0;
+  const int cc = second ? c - p.C0 : c;
+  float sum[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = min(p0 + pix_per_chunk, p.P);
+  for (int px = p0 + py; px < p1; px += PY) {
+    float v[8];
+    load8(base, p.in_f32, ((size_t)n * p.P + px) * cs + cc, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[e] += v[e]; sq[e] += v[e] * v[e]; }
+  }
+  // fold the 8 channels into (at most two) groups, then one LDS atomic per group per thread
+  const int g0 = c / cpg, g1 = (c + 7) / cpg;
+  float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if ((c + e) / cpg == g0) { a0 += sum[e]; q0 += sq[e]; } else { a1 += sum[e]; q1 += sq[e]; }
+  }
+  atomicAdd(&s_sum[g0], a0);
+  atomicAdd(&s_sq[g0], q0);
+  if (g1 != g0) { atomicAdd(&s_sum[g1], a1); atomicAdd(&s_sq[g1], q1); }
+  __syncthreads();
+  if (tid < 32) {
+    float* o = p.partial + (((size_t)n * p.nchunk + chunk) * 32 + tid) * 2;
+    o[0] = s_sum[tid];
+    o[1] = s_sq[tid];
+  }
+}
+
+// grid: (pixel blocks, B); block 256: each thread handles 8-channel chunks
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_block) {
+  __shared__ float s_mean[32], s_rstd[32];
+  const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid < 32) {
+    float s = 0.f, q = 0.f;
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+      const float* o = p.partial + (((size_t)n * p.nchunk + ch) * 32 + tid) * 2;
+      s += o[0];
+      q += o[1];
+    }
+    const float cnt = (float)cpg * (float)p.P;
+    const float mean = s / cnt;
+    float var = q / cnt - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_mean[tid] = mean;
+    s_rstd[tid] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, p.P);
+  const int items = (p1 - p0) * C8;
+  for (int it = tid; it < items; it += 256) {
+    const int px = p0 + it / C8, c8 = it % C8;
+    const int c = c8 * 8;
+    const bool second = c >= p.C0;
+    const void* base = second ? p.x1 : p.x0;
+    const int cs = second ? p.C1 : p.C0;
+    const int cc = second ? c - p.C0 : c;
+    float v[8];
+    load8(base, p.in_f32, ((size_t)n * p.P + px) * cs + cc, v);
+    const f32x4 ga = *(const f32x4*)(p.gamma + c), gb = *(const f32x4*)(p.gamma + c + 4);
+    const f32x4 ba = *(const f32x4*)(p.beta + c), bb = *(const f32x4*)(p.beta + c + 4);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c + e) / cpg;
+      const float gam = e < 4 ? ga[e] : gb[e - 4];
+      const float bet = e < 4 ? ba[e] : bb[e - 4];
+      float y = (v[e] - s_mean[g]) * s_rstd[g] * gam + bet;
+      if (p.silu) y = y / (1.f + __expf(-y));
+      o[e] = (f16)y;
+    }
+    *(f16x8*)(p.y + ((size_t)n * p.P + px) * C + c) = o;
+  }
+}
+
+// one wave per row; C in {320, 640, 1280} -> 40/80/160 chunks of 8 -> up to 3 chunks per lane
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int C8 = p.C / 8;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = lane + i * 64;
+    if (c8 < C8) {
+      load8(p.x, p.in_f32, (size_t)row * p.C + c8 * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = lane + i * 64;
+    if (c8 < C8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)p.C + p.eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = lane + i * 64;
+    if (c8 < C8) {
+      const int c = c8 * 8;
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * p.gamma[c + e] + p.beta[c + e]);
+      *(f16x8*)(p.y + (size_t)row * p.C + c) = o;
+    }
+  }
+}
+
+}  // namespace
+
+int sdmi_gn_nchunk(int P) {
+  int n = (P + 63) / 64;      // ~64 pixels per chunk
+  if (n > 64) n = 64;
+  if (n < 1) n = 1;
+  return n;
+}
+
+int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
+  const int C = a.C0 + a.C1;
+  SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "groupnorm: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
+  SDMI_REQUIRE(C / 8 <= 320, "groupnorm: C=%d too large (max 2560)", C);
+  SDMI_REQUIRE(a.partial && a.y && a.x0 && a.gamma && a.beta, "groupnorm: null pointer");
+  SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
+  const int C8 = C / 8;
+  int PY = 256 / C8;
+  if (PY < 1) PY = 1;
+  const int ppc = (a.P + a.nchunk - 1) / a.nchunk;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(C8 * PY), 0, st, a, PY, ppc);
+  SDMI_CHECK_HIP(hipGetLastError());
+  // apply: ~2048 items (8-channel chunks) per thread block iteration budget
+  int ppb = (256 * 8) / C8;
+  if (ppb < 1) ppb = 1;
+  const int nblk = (a.P + ppb - 1) / ppb;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a, ppb);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st) {
+  SDMI_REQUIRE(a.C % 8 == 0 && a.C <= 8 * 64 * 3, "layernorm: C=%d unsupported", a.C);
+  SDMI_REQUIRE(a.x && a.y && a.gamma && a.beta && a.M > 0, "layernorm: bad args");
+  const int nch = (a.C / 8 + 63) / 64;
+  dim3 grid((a.M + 3) / 4), block(256);
+  if (nch == 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, a);
+  else if (nch == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, a);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}

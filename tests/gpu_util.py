@@ -1,0 +1,98 @@
+"""Helpers for -m gpu tests: thin wrappers over the C ABI (kernel-level entry points)."""
+import ctypes as C
+import json
+import os
+import time
+
+import torch
+
+from pytorch_stable_diffusion_amd import _native as N
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def log_metric(**kw):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        kw["ts"] = time.time()
+        with open(os.path.join(OUT, "test_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
+    """OIHW (or [O][I]) cuda tensor -> packed [O][kh][kw][I] fp16 via the library's packer."""
+    lib = N.load()
+    if w.dim() == 2:
+        O, I, ks = w.shape[0], w.shape[1], 1
+    else:
+        O, I, ks = w.shape[0], w.shape[1], w.shape[2]
+    o_keep = O if o_keep is None else o_keep
+    out = torch.empty((o_keep, ks * ks * I), dtype=torch.float16, device=w.device)
+    code = N.SDMI_F32 if w.dtype == torch.float32 else N.SDMI_F16
+    N.check(lib.sdmi_op_pack_conv(N.ptr(w.contiguous()), code, N.ptr(out), O, I, ks, o_keep, N.cur_stream()), "pack")
+    return out
+
+
+def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
+          out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False):
+    """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
+    lib = N.load()
+    d = N.GemmDesc()
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    Nn = w_packed.shape[0]
+    K = w_packed.shape[1]
+    M = B * Ho * Wo
+    ncols = Nn if out_t is None else max(nt0, 8)
+    out = torch.zeros((M, ncols), dtype=torch.float32 if out_f32 else torch.float16, device=a0.device)
+    out16 = torch.zeros((M, ncols), dtype=torch.float16, device=a0.device) if (want16 and out_f32) else None
+    d.a0 = a0.data_ptr(); d.a1 = 0 if a1 is None else a1.data_ptr()
+    d.c0, d.c1, d.hs, d.ws, d.ho, d.wo = c0, c1, Hs, Ws, Ho, Wo
+    d.ups, d.stride, d.pad, d.ks = ups, stride, (1 if ks == 3 else 0), ks
+    d.M, d.N, d.K = M, Nn, K
+    d.w = w_packed.data_ptr()
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.res = 0 if res is None else res.data_ptr()
+    d.res_f32 = int(res is not None and res.dtype == torch.float32)
+    d.ldr = 0 if res is None else res.shape[-1]
+    d.out = out.data_ptr(); d.out_f32 = int(out_f32); d.ldc = ncols
+    d.out16 = 0 if out16 is None else out16.data_ptr()
+    d.out_t = 0 if out_t is None else out_t.data_ptr()
+    d.nt0, d.S, d.ldt = nt0, S, ldt
+    d.cfg, d.ksplit = cfg, ksplit
+    N.check(lib.sdmi_op_gemm(C.byref(d), N.cur_stream()), "sdmi_op_gemm")
+    torch.cuda.synchronize()
+    return (out, out16) if want16 else out
+
+
+def attention(q, k, vt, B, H, d, Sq, Skv, k_batch_stride=None):
+    lib = N.load()
+    o = torch.zeros((B * Sq, H * d), dtype=torch.float16, device=q.device)
+    kbs = Skv if k_batch_stride is None else k_batch_stride
+    N.check(lib.sdmi_op_attention(N.ptr(q), q.shape[-1], N.ptr(k), k.shape[-1], kbs, N.ptr(vt), vt.shape[-1],
+                                  N.ptr(o), o.shape[-1], B, H, d, Sq, Skv, N.cur_stream()), "sdmi_op_attention")
+    torch.cuda.synchronize()
+    return o
+
+
+def groupnorm(x0, x1, gamma, beta, eps, silu):
+    lib = N.load()
+    B, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    y = torch.empty((B, H, W, c0 + c1), dtype=torch.float16, device=x0.device)
+    N.check(lib.sdmi_op_groupnorm(N.ptr(x0), N.ptr(x1), int(x0.dtype == torch.float32), c0, c1, B, H * W,
+                                  N.ptr(gamma), N.ptr(beta), eps, int(silu), N.ptr(y), N.cur_stream()), "gn")
+    torch.cuda.synchronize()
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = N.load()
+    M, Cc = x.shape
+    y = torch.empty((M, Cc), dtype=torch.float16, device=x.device)
+    N.check(lib.sdmi_op_layernorm(N.ptr(x), int(x.dtype == torch.float32), M, Cc, N.ptr(gamma), N.ptr(beta), eps,
+                                  N.ptr(y), N.cur_stream()), "ln")
+    torch.cuda.synchronize()
+    return y

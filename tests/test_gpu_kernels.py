@@ -1,0 +1,226 @@
+"""Kernel-level parity (-m gpu): each HIP kernel through the C ABI vs a plain fp32/fp64 torch-CPU
+restatement of the same op on the same fp16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import gpu_util as G
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cfgs():
+    from pytorch_stable_diffusion_amd import _native as N
+    return list(range(N.load().sdmi_gemm_num_configs()))
+
+
+def test_library_loaded_is_in_tree():
+    from pytorch_stable_diffusion_amd import _native as N
+    lib = N.load()
+    assert lib.sdmi_version() >= 100
+    assert "pytorch_stable_diffusion_amd/lib/libsdmi.so" in N.lib_path()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_gemm_exact_integers(cfg):
+    """MFMA fragment layouts: small-integer operands make every product/sum exact, so the result must
+    equal the integer matmul bit for bit (asymmetric operands catch transposed/permuted layouts)."""
+    torch.manual_seed(cfg)
+    M, Nn, K = 200, 136, 128           # ragged M and N exercise the bounds paths
+    a = torch.randint(-2, 3, (M, K)).to(torch.float16)
+    w = torch.randint(-2, 3, (Nn, K)).to(torch.float16)
+    w[:, 0] = torch.arange(Nn) % 3 - 1    # asymmetric
+    ref = a.double() @ w.double().t()
+    out = G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, cfg=cfg)
+    assert torch.equal(out.cpu().double(), ref), f"cfg {cfg}: max diff {(out.cpu().double()-ref).abs().max()}"
+
+
+@pytest.mark.parametrize("M,Nn,K,ksplit", [(8192, 320, 320, 1), (512, 1280, 2560, 4), (128, 1280, 1280, 8),
+                                           (154, 640, 768, 1), (2048, 1920, 640, 1)])
+def test_gemm_random_bias_residual(M, Nn, K, ksplit):
+    g = torch.Generator().manual_seed(M + Nn + K)
+    a = (torch.randn((M, K), generator=g)).to(torch.float16)
+    w = (torch.randn((Nn, K), generator=g) / math.sqrt(K)).to(torch.float16)
+    bias = torch.randn((Nn,), generator=g)
+    res = torch.randn((M, Nn), generator=g)
+    ref = a.double() @ w.double().t() + bias.double() + res.double()
+    for cfg in [-1] + _cfgs():
+        out, out16 = G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias.to(DEV),
+                             res=res.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit, want16=True)
+        err = (out.cpu().double() - ref).abs().max().item()
+        G.log_metric(test="gemm_random", M=M, N=Nn, K=K, cfg=cfg, ksplit=ksplit, max_abs_err=err)
+        assert err < 2e-3, f"cfg {cfg}: fp32-out max abs err {err}"
+        assert (out16.cpu().double() - ref).abs().max().item() < 8e-3
+        # fp16 residual / fp16 output path
+        out_h = G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias.to(DEV),
+                        res=res.to(DEV).half(), out_f32=False, cfg=cfg, ksplit=ksplit)
+        ref_h = a.double() @ w.double().t() + bias.double() + res.half().double()
+        assert (out_h.cpu().double() - ref_h).abs().max().item() < 8e-3
+
+
+def _conv_ref(x_nhwc, w_oihw, stride, ups):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    ks = w_oihw.shape[-1]
+    return F.conv2d(x.double(), w_oihw.double(), stride=stride, padding=1 if ks == 3 else 0).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=16, W=16, C0=128, C1=0, Co=128, ks=3, stride=1, ups=0),
+    dict(B=2, H=16, W=16, C0=64, C1=0, Co=192, ks=3, stride=2, ups=0),
+    dict(B=2, H=8, W=8, C0=128, C1=0, Co=64, ks=3, stride=1, ups=1),
+    dict(B=2, H=12, W=12, C0=128, C1=64, Co=320, ks=3, stride=1, ups=0),     # concat, ragged tiles
+    dict(B=1, H=10, W=6, C0=64, C1=128, Co=72, ks=1, stride=1, ups=0),       # 1x1 on concat
+    dict(B=2, H=9, W=9, C0=64, C1=0, Co=64, ks=3, stride=2, ups=0),          # odd size, stride 2
+])
+def test_conv_implicit_gemm(case):
+    c = case
+    g = torch.Generator().manual_seed(c["C0"] * 7 + c["Co"])
+    x0 = torch.randn((c["B"], c["H"], c["W"], c["C0"]), generator=g).half()
+    x1 = torch.randn((c["B"], c["H"], c["W"], c["C1"]), generator=g).half() if c["C1"] else None
+    cin = c["C0"] + c["C1"]
+    w = (torch.randn((c["Co"], cin, c["ks"], c["ks"]), generator=g) / math.sqrt(cin * c["ks"] ** 2)).half().float()
+    xin = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = _conv_ref(xin, w, c["stride"], c["ups"])
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    wp = G.pack_conv(w.to(DEV))
+    for cfg in [-1] + _cfgs():
+        for ksplit in (1, 3):
+            out = G.igemm(x0.to(DEV), wp, B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"],
+                          ups=c["ups"], a1=None if x1 is None else x1.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit)
+            err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
+            G.log_metric(test="conv", case=str(c), cfg=cfg, ksplit=ksplit, max_abs_err=err)
+            assert err < 2e-3, f"{c} cfg {cfg} ksplit {ksplit}: max abs err {err}"
+
+
+def test_gemm_transposed_tail():
+    """in_proj epilogue: columns [0,2C) row-major, columns [2C,3C) written as V^T[b][c][s]."""
+    B, S, Cc = 2, 192, 128
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((B * S, Cc), generator=g).half()
+    w = (torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    ref = a.double() @ w.double().t()
+    ldt = 256
+    for cfg in _cfgs():
+        for ksplit in (1, 2):
+            vt = torch.zeros((B * Cc, ldt), dtype=torch.float16, device=DEV)
+            out = G.igemm(a.to(DEV).view(1, B * S, 1, Cc), w.to(DEV), B=1, Hs=B * S, Ws=1, Ho=B * S, Wo=1, cfg=cfg,
+                          ksplit=ksplit, out_t=vt, nt0=2 * Cc, S=S, ldt=ldt)
+            assert (out.cpu().double() - ref[:, :2 * Cc]).abs().max().item() < 8e-3
+            v_ref = ref[:, 2 * Cc:].view(B, S, Cc).permute(0, 2, 1)        # (B, C, S)
+            got = vt.cpu().double().view(B, Cc, ldt)
+            assert (got[:, :, :S] - v_ref).abs().max().item() < 8e-3, f"cfg {cfg} ksplit {ksplit}"
+            assert got[:, :, S:].abs().max().item() == 0.0
+
+
+def _attn_ref(q, k, v, B, Hh, d, Sq, Skv):
+    qh = q.double().view(B, Sq, Hh, d).permute(0, 2, 1, 3)
+    kh = k.double().view(B, Skv, Hh, d).permute(0, 2, 1, 3)
+    vh = v.double().view(B, Skv, Hh, d).permute(0, 2, 1, 3)
+    w = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    return (w @ vh).permute(0, 2, 1, 3).reshape(B * Sq, Hh * d)
+
+
+@pytest.mark.parametrize("d,Sq,Skv", [(40, 256, 256), (40, 1024, 1024), (80, 256, 256), (160, 64, 64),
+                                      (160, 256, 256), (40, 200, 77), (80, 64, 77), (160, 144, 144),
+                                      (40, 4096, 4096)])
+def test_flash_attention(d, Sq, Skv):
+    B, Hh = 2, 8
+    if Sq == 4096:
+        Hh = 2
+    Cc = Hh * d
+    g = torch.Generator().manual_seed(d + Sq)
+    q = torch.randn((B * Sq, Cc), generator=g).half()
+    k = torch.randn((B * Skv, Cc), generator=g).half()
+    v = torch.randn((B * Skv, Cc), generator=g).half()
+    ref = _attn_ref(q, k, v, B, Hh, d, Sq, Skv)
+    ldvt = ((Skv + 63) // 64) * 64
+    vt = torch.zeros((B * Cc, ldvt), dtype=torch.float16)
+    vt.view(B, Cc, ldvt)[:, :, :Skv] = v.view(B, Skv, Cc).permute(0, 2, 1)
+    out = G.attention(q.to(DEV), k.to(DEV), vt.to(DEV), B, Hh, d, Sq, Skv)
+    err = (out.cpu().double() - ref).abs().max().item()
+    G.log_metric(test="attention", d=d, Sq=Sq, Skv=Skv, max_abs_err=err)
+    assert err < 4e-3, f"d={d} Sq={Sq} Skv={Skv}: max abs err {err}"
+
+
+def test_flash_attention_large_logits():
+    """Online-softmax rescale path: one key dominates late in the sequence (max jumps between tiles)."""
+    B, Hh, d, S = 1, 8, 40, 512
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn((B * S, Hh * d), generator=g).half()
+    k = torch.randn((B * S, Hh * d), generator=g).half()
+    v = torch.randn((B * S, Hh * d), generator=g).half()
+    k[300] = (q[7] * 4).half()         # spike: query 7 . key 300 >> others, in tile 4
+    k[40] = (q[100] * 3).half()
+    ref = _attn_ref(q, k, v, B, Hh, d, S, S)
+    vt = v.view(B, S, Hh * d).permute(0, 2, 1).contiguous().view(B * Hh * d, S)
+    out = G.attention(q.to(DEV), k.to(DEV), vt.to(DEV), B, Hh, d, S, S)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 4e-3, f"max abs err {err}"
+
+
+@pytest.mark.parametrize("C0,C1,P,in_f32,silu,eps", [(320, 0, 64, True, True, 1e-5), (640, 320, 256, False, True, 1e-5),
+                                                     (1280, 640, 64, True, True, 1e-5), (320, 0, 4096, True, False, 1e-6),
+                                                     (1280, 1280, 64, False, True, 1e-5)])
+def test_groupnorm(C0, C1, P, in_f32, silu, eps):
+    B = 2
+    Hh = int(math.isqrt(P))
+    g = torch.Generator().manual_seed(C0 + C1 + P)
+    dt = torch.float32 if in_f32 else torch.float16
+    x0 = (torch.randn((B, Hh, Hh, C0), generator=g) * 2 + 0.5).to(dt)
+    x1 = (torch.randn((B, Hh, Hh, C1), generator=g) * 0.5 - 1).to(dt) if C1 else None
+    Cc = C0 + C1
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    x = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = F.group_norm(x.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    y = G.groupnorm(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), eps, silu)
+    err = (y.cpu().double() - ref).abs().max().item()
+    G.log_metric(test="groupnorm", C0=C0, C1=C1, P=P, max_abs_err=err)
+    assert err < 6e-3, f"max abs err {err}"
+
+
+@pytest.mark.parametrize("M,Cc,in_f32", [(128, 320, True), (300, 640, False), (64, 1280, True)])
+def test_layernorm(M, Cc, in_f32):
+    g = torch.Generator().manual_seed(M + Cc)
+    x = (torch.randn((M, Cc), generator=g) * 3 + 1).to(torch.float32 if in_f32 else torch.float16)
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    ref = F.layer_norm(x.double(), (Cc,), gamma.double(), beta.double(), 1e-5)
+    y = G.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 6e-3, f"max abs err {err}"
+
+
+def test_cfg_ddpm_step_bit_exact_vs_oracle():
+    """Fused CFG + DDPM step kernel vs the oracle's restatement of sd/pipeline.py:230-233 + sd/ddpm.py:102-139
+    on identical eps: bit-exact for every step of the 20- and 50-step schedules probed."""
+    from oracle import ddpm_ref
+    from pytorch_stable_diffusion_amd import _native as N
+    from pytorch_stable_diffusion_amd.ddpm import DDPMSampler
+    lat = H.seeded((1, 4, 16, 16), 21)
+    eps = H.seeded((2, 4, 16, 16), 22)
+    for n in (20, 50):
+        ref = ddpm_ref.RefSchedule()
+        ref.set_inference_timesteps(n)
+        smp = DDPMSampler(torch.Generator().manual_seed(0))
+        smp.set_inference_timesteps(n)
+        ts = ref.timesteps.tolist()
+        for t in (ts[0], ts[1], ts[n // 2], ts[-2], ts[-1]):
+            noise = H.seeded((1, 4, 16, 16), 23 + t) if t > 0 else None
+            cond, uncond = eps.chunk(2)
+            guided = 7.5 * (cond - uncond) + uncond
+            want = ref.step(t, lat.clone(), guided, noise)
+            got = lat.clone().to(DEV)
+            N.cfg_ddpm_step(eps.to(DEV), True, 7.5, got, None if noise is None else noise.to(DEV),
+                            smp.step_coefficients(t))
+            torch.cuda.synchronize()
+            assert torch.equal(got.cpu(), want), f"n={n} t={t}: max diff {(got.cpu()-want).abs().max()}"
