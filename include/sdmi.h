@@ -91,6 +91,12 @@ int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, con
                         const float* x1_dev, int c1, int batch, int h, int w, const float* time_dev,
                         float* out_dev, void* stream);
 
+/* Per-launch HIP-event profiling of the forward (bench.py roofline): enable, run forwards, then read
+ * summed milliseconds / algorithmic FLOPs / launch counts for class 0 = implicit-GEMM conv+linear,
+ * 1 = flash attention, 2 = norms.  Events are recorded on the forward's own stream. */
+int sdmi_unet_profile(sdmi_unet* u, int enable);
+int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_class, int* launches_by_class);
+
 /* Number of kernel launches enqueued by the last sdmi_unet_forward, and bytes of packed weights. */
 int sdmi_unet_last_launch_count(const sdmi_unet* u);
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);

@@ -50,6 +50,8 @@ _SIGNATURES = {
                                          C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "sdmi_unet_run_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdmi_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "sdmi_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "sdmi_unet_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
     "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -208,6 +210,17 @@ class UNetHandle:
                                             ptr(None if x1 is None else x1.contiguous()), c1, B, H, W,
                                             ptr(time), ptr(out), cur_stream()), "sdmi_unet_run_block")
         return out
+
+    def profile(self, enable: bool):
+        check(self._lib.sdmi_unet_profile(self._h, int(enable)), "sdmi_unet_profile")
+
+    def profile_read(self):
+        ms = (C.c_double * 3)()
+        fl = (C.c_double * 3)()
+        nl = (C.c_int * 3)()
+        check(self._lib.sdmi_unet_profile_read(self._h, ms, fl, nl), "sdmi_unet_profile_read")
+        names = ("igemm", "attention", "norm")
+        return {n: dict(ms=ms[i], flops=fl[i], launches=nl[i]) for i, n in enumerate(names)}
 
     @property
     def last_launch_count(self) -> int:

@@ -112,6 +112,21 @@ struct sdmi_unet {
   std::map<ShapeKey, Plan> plans;
   int launches = 0;
   hipStream_t st = nullptr;
+  // optional per-launch HIP-event profiling (bench roofline): class 0 = igemm, 1 = attention, 2 = other
+  bool profiling = false;
+  struct ProfRec { hipEvent_t e0, e1; int cls; double flops; };
+  std::vector<ProfRec> prof;
+  void prof_begin(int cls, double flops) {
+    if (!profiling) return;
+    ProfRec r; r.cls = cls; r.flops = flops;
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, st);
+    prof.push_back(r);
+  }
+  void prof_end() {
+    if (!profiling) return;
+    (void)hipEventRecord(prof.back().e1, st);
+  }
 
   ~sdmi_unet() {
     for (void* p : owned) (void)hipFree(p);
@@ -260,7 +275,9 @@ struct sdmi_unet {
     }
     a.ksplit = it->second.ksplit;
     const int nl = a.ksplit > 1 ? 2 : 1;
+    prof_begin(0, 2.0 * a.M * a.N * a.K);
     TRY(sdmi_launch_gemm(a, it->second.cfg, st));
+    prof_end();
     launches += nl;
     return SDMI_OK;
   }
@@ -338,7 +355,9 @@ struct sdmi_unet {
     g.B = x.B; g.P = x.H * x.W;
     g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
     g.y = y->h; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
+    prof_begin(2, 0.0);
     TRY(sdmi_launch_groupnorm(g, st));
+    prof_end();
     launches += 2;
     return SDMI_OK;
   }
@@ -349,7 +368,9 @@ struct sdmi_unet {
     l.x = x.f ? (const void*)x.f : (const void*)x.h;
     l.in_f32 = x.f != nullptr;
     l.M = x.M(); l.C = x.C; l.gamma = w.gamma; l.beta = w.beta; l.eps = 1e-5f; l.y = y->h;
+    prof_begin(2, 0.0);
     TRY(sdmi_launch_layernorm(l, st));
+    prof_end();
     launches += 1;
     return SDMI_OK;
   }
@@ -393,7 +414,9 @@ struct sdmi_unet {
     t.q = q; t.ldq = ldq; t.k = k; t.ldk = ldk; t.k_batch_stride = kbs; t.vt = vt; t.ldvt = ldvt;
     t.o = o; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero;
     t.scale = 1.f / sqrtf((float)d);
+    prof_begin(1, 4.0 * B * kHeads * (double)Sq * Skv * d);
     TRY(sdmi_launch_attention(t, st));
+    prof_end();
     launches += 1;
     return SDMI_OK;
   }
@@ -830,6 +853,28 @@ int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, con
     return SDMI_EINVAL;
   }
   return export_act(u, y, out_dev);
+}
+
+int sdmi_unet_profile(sdmi_unet* u, int enable) {
+  if (!u) { sdmi_set_error("profile: null handle"); return SDMI_EINVAL; }
+  for (auto& r : u->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  u->prof.clear();
+  u->profiling = enable != 0;
+  return SDMI_OK;
+}
+
+int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_class, int* launches_by_class) {
+  if (!u || !ms_by_class || !flops_by_class || !launches_by_class) { sdmi_set_error("profile_read: null argument"); return SDMI_EINVAL; }
+  for (int c = 0; c < 3; ++c) { ms_by_class[c] = 0; flops_by_class[c] = 0; launches_by_class[c] = 0; }
+  for (auto& r : u->prof) {
+    SDMI_CHECK_HIP(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    SDMI_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    ms_by_class[r.cls] += ms;
+    flops_by_class[r.cls] += r.flops;
+    launches_by_class[r.cls] += 1;
+  }
+  return SDMI_OK;
 }
 
 int sdmi_unet_last_launch_count(const sdmi_unet* u) { return u ? u->launches : 0; }

@@ -93,6 +93,20 @@ class Diffusion:
         CFG combine + DDPM update."""
         self.handle().denoise_step(latents, step_idx, do_cfg, cfg_scale, noise, coef)
 
+    @torch.no_grad()
+    def denoise_native(self, latents: torch.Tensor, context: torch.Tensor, sampler, timesteps, do_cfg: bool,
+                       cfg_scale: float) -> torch.Tensor:
+        """The whole loop of sd/pipeline.py:205-237 as fused native steps; noise is drawn from the
+        sampler's shared generator in the reference's order (one draw per step with t > 0)."""
+        from .pipeline import get_time_embedding
+        lat = latents.to(self._device, torch.float32).contiguous().clone()
+        self.set_context(context)
+        self.set_schedule(torch.cat([get_time_embedding(t) for t in timesteps]))
+        for i, t in enumerate(timesteps):
+            noise = sampler.draw_noise(lat.shape, self._device) if t > 0 else None
+            self.step(lat, i, do_cfg, cfg_scale, noise, sampler.step_coefficients(t))
+        return lat
+
     # ---- reference call convention -------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, latent: torch.Tensor, context: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
