@@ -20,15 +20,17 @@
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int NS_>
 struct Cfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static constexpr int RA = BM * 8 / NT, RB = BN * 8 / NT;
   static constexpr int CS_BYTES = BM * BN * 4;
-  static constexpr int LDS = (2 * STAGE > CS_BYTES) ? 2 * STAGE : CS_BYTES;
+  static constexpr int LDS = (NS * STAGE > CS_BYTES) ? NS * STAGE : CS_BYTES;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
 };
@@ -108,12 +110,15 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       const int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
       const bool v = a_ok[i] && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
       const int pix = a_pix0[i] + (ih >> p.ups) * p.Ws + (iw >> p.ups);
-      const f16* g = v ? base + (size_t)pix * cs + cc + a_gch[i] : p.zero + a_gch[i];
+      const f16* gr = base + ((size_t)(unsigned)(pix * cs + cc) + a_gch[i]);
+      const f16* gz = p.zero + a_gch[i];
+      const f16* g = v ? gr : gz;
       glds16(g, sa + (i * NW + wave) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const f16* g = b_ok[i] ? b_ptr[i] : p.zero + b_gch[i];
+      const f16* gz = p.zero + b_gch[i];
+      const f16* g = b_ok[i] ? b_ptr[i] : gz;
       glds16(g, sb + (i * NW + wave) * 1024);
       b_ptr[i] += 64;
     }
@@ -138,13 +143,25 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (kt0 < kt1) {
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int t = kt0; t < kt1; ++t) {
-      if (t + 1 < kt1) stage(cur ^ 1);
+  // ---- main loop: NS-deep LDS ring, loads stay in flight across barriers (counted vmcnt) --------
+  //   iteration t: wait until the loads of step t have landed (later groups may stay in flight),
+  //   barrier (also closes the WAR window on the buffer read in iteration t-1), issue step t+NS-1
+  //   into that buffer, then MFMA over buffer t % NS.
+  constexpr int NS = C::NS;
+  constexpr int G = RA + RB;              // LDS-DMA instructions per wave per stage
+  const int nk = kt1 - kt0;
+  {
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) stage(s);
+    int cur = 0, nxt = NS - 1;
+    for (int t = 0; t < nk; ++t) {
+      const int rem = nk - 1 - t;           // groups issued after step t
+      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + NS - 1 < nk) stage(nxt);
       const char* As = smem + cur * C::STAGE + a_row_off;
       const char* Bs = smem + cur * C::STAGE + C::A_BYTES + b_row_off;
 #pragma unroll
@@ -160,10 +177,11 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
           for (int j = 0; j < FN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, row-major [BM][BN]) -> coalesced global ----------
@@ -244,8 +262,19 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       f16x8 o16;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o16[e] = (f16)(Cs[(r8 * 8 + e) * BN + col] + bv);
-      const int b = m / p.S, s = m - b * p.S;
-      *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
+      if ((p.S & 7) == 0) {
+        const int b = m / p.S, s = m - b * p.S;
+        *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
+      } else {   // tiny maps (S not a multiple of 8): element-wise, rows may straddle images
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int me = m + e;
+          if (me < p.M) {
+            const int b = me / p.S, s = me - b * p.S;
+            p.outT[((size_t)b * Ct + (n - p.nt0)) * p.ldt + s] = o16[e];
+          }
+        }
+      }
     }
   }
 }
@@ -302,23 +331,21 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   }
 }
 
-typedef Cfg<128, 128, 2, 2> C128x128;
-typedef Cfg<128, 64, 2, 2> C128x64;
-typedef Cfg<64, 128, 2, 2> C64x128;
-typedef Cfg<64, 64, 2, 2> C64x64;
-typedef Cfg<256, 128, 4, 2> C256x128;
-typedef Cfg<128, 256, 2, 4> C128x256;
-
 struct CfgInfo {
   const char* name;
-  int BM, BN, NT, LDS;
+  int BM, BN, NS, NT, LDS;
   void (*kern)(GemmArgs);
 };
 
-#define CFG_ENTRY(C) {#C, C::BM, C::BN, C::NT, C::LDS, igemm_kernel<C>}
+#define CFG_ENTRY(BM, BN, WM, WN, NS) \
+  {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
 const CfgInfo kCfgs[] = {
-    CFG_ENTRY(C128x128), CFG_ENTRY(C128x64), CFG_ENTRY(C64x128),
-    CFG_ENTRY(C64x64),   CFG_ENTRY(C256x128), CFG_ENTRY(C128x256),
+    CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
+    CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
+    CFG_ENTRY(64, 128, 2, 2, 2),  CFG_ENTRY(64, 128, 2, 2, 4),
+    CFG_ENTRY(64, 64, 2, 2, 2),   CFG_ENTRY(64, 64, 2, 2, 3),  CFG_ENTRY(64, 64, 2, 2, 4),
+    CFG_ENTRY(256, 128, 4, 2, 2), CFG_ENTRY(256, 128, 4, 2, 3),
+    CFG_ENTRY(128, 256, 2, 4, 2), CFG_ENTRY(128, 256, 2, 4, 3),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};
@@ -328,11 +355,16 @@ bool g_attr_done[kNumCfgs] = {};
 int sdmi_gemm_num_cfgs() { return kNumCfgs; }
 const char* sdmi_gemm_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?"; }
 
+void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
+  *bm = kCfgs[cfg].BM;
+  *bn = kCfgs[cfg].BN;
+}
+
 static int pick_cfg(const GemmArgs& a) {
   // heuristic default (the UNet plan autotunes over all cfgs x split-K instead)
-  if (a.M <= 64) return 3;
-  if (a.N % 128 != 0 && a.N % 64 == 0 && a.N < 512) return 1;
-  return 0;
+  if (a.M <= 64) return 9;                                         // t64x64s4
+  if (a.N % 128 != 0 && a.N % 64 == 0 && a.N < 512) return 4;      // t128x64s4
+  return 1;                                                        // t128x128s3
 }
 
 size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int /*cfg*/, int ksplit) {
@@ -353,7 +385,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   const CfgInfo& c = kCfgs[cfg];
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
-    SDMI_REQUIRE(a.S % 8 == 0 && a.ldt % 8 == 0, "gemm: transposed tail needs S,ldt multiples of 8");
+    SDMI_REQUIRE(a.S > 0 && a.ldt % 8 == 0, "gemm: transposed tail needs S > 0 and ldt a multiple of 8");
   }
   const int nkt = a.K / 64;
   GemmArgs p = a;

@@ -24,15 +24,14 @@ __device__ __forceinline__ void load8(const void* base, int is_f32, size_t elem_
   }
 }
 
-// grid: (nchunk, B); block: (C/8) * PY threads (<= 320), thread = (channel chunk c8, pixel lane py)
+// grid: (nchunk, B); block: (C/8) * PY threads (<= 320), thread = (pixel lane py, channel chunk c8).
+// Deterministic: per-thread partials go to LDS and each group is summed in a fixed order.
 __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix_per_chunk) {
-  __shared__ float s_sum[32], s_sq[32];
+  __shared__ float s_part[320 * 4];     // per thread: {sum0, sq0, sum1, sq1} (first / second group of its chunk)
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
   const int tid = threadIdx.x;
   const int c8 = tid % C8, py = tid / C8;
   const int n = blockIdx.y, chunk = blockIdx.x;
-  if (tid < 32) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-  __syncthreads();
   const int c = c8 * 8;
   const bool second = c >= p.C0;
   const void* base = second ? p.x1 : p.x0;
@@ -43,43 +42,65 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
   for (int e = 0; e < 8; ++e) { sum[e] = 0.f; sq[e] = 0.f; }
   const int p0 = chunk * pix_per_chunk;
   const int p1 = min(p0 + pix_per_chunk, p.P);
+#pragma unroll 4
   for (int px = p0 + py; px < p1; px += PY) {
     float v[8];
     load8(base, p.in_f32, ((size_t)n * p.P + px) * cs + cc, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sum[e] += v[e]; sq[e] += v[e] * v[e]; }
   }
-  // fold the 8 channels into (at most two) groups, then one LDS atomic per group per thread
-  const int g0 = c / cpg, g1 = (c + 7) / cpg;
+  const int g0 = c / cpg;
   float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     if ((c + e) / cpg == g0) { a0 += sum[e]; q0 += sq[e]; } else { a1 += sum[e]; q1 += sq[e]; }
   }
-  atomicAdd(&s_sum[g0], a0);
-  atomicAdd(&s_sq[g0], q0);
-  if (g1 != g0) { atomicAdd(&s_sum[g1], a1); atomicAdd(&s_sq[g1], q1); }
+  s_part[tid * 4 + 0] = a0; s_part[tid * 4 + 1] = q0; s_part[tid * 4 + 2] = a1; s_part[tid * 4 + 3] = q1;
   __syncthreads();
   if (tid < 32) {
-    float* o = p.partial + (((size_t)n * p.nchunk + chunk) * 32 + tid) * 2;
-    o[0] = s_sum[tid];
-    o[1] = s_sq[tid];
+    const int g = tid;
+    const int lo = (g * cpg) / 8, hi = ((g + 1) * cpg - 1) / 8;
+    float s = 0.f, q = 0.f;
+    for (int k = lo; k <= hi; ++k) {
+      const int kg0 = (k * 8) / cpg;
+      const int sel = (kg0 == g) ? 0 : 2;       // chunk k contributes its first or its second part to g
+      for (int y = 0; y < PY; ++y) {
+        const float* e = s_part + (y * C8 + k) * 4 + sel;
+        s += e[0];
+        q += e[1];
+      }
+    }
+    float* o = p.partial + (((size_t)n * p.nchunk + chunk) * 32 + g) * 2;
+    o[0] = s;
+    o[1] = q;
   }
 }
 
-// grid: (pixel blocks, B); block 256: each thread handles 8-channel chunks
+// grid: (pixel blocks, B); block 256.  Phase 1: all 256 threads reduce the chunk partials (fixed
+// order) to mean/rstd per group; phase 2: normalise (+SiLU) 8-channel chunks.
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_block) {
+  __shared__ float s_red[8][32][2];
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  if (tid < 32) {
+  {
+    const int g = tid & 31, sl = tid >> 5;
     float s = 0.f, q = 0.f;
-    for (int ch = 0; ch < p.nchunk; ++ch) {
-      const float* o = p.partial + (((size_t)n * p.nchunk + ch) * 32 + tid) * 2;
+#pragma unroll 4
+    for (int ch = sl; ch < p.nchunk; ch += 8) {
+      const float* o = p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2;
       s += o[0];
       q += o[1];
     }
+    s_red[sl][g][0] = s;
+    s_red[sl][g][1] = q;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) { s += s_red[sl][tid][0]; q += s_red[sl][tid][1]; }
     const float cnt = (float)cpg * (float)p.P;
     const float mean = s / cnt;
     float var = q / cnt - mean * mean;
@@ -168,10 +189,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 }  // namespace
 
 int sdmi_gn_nchunk(int P) {
-  int n = (P + 63) / 64;      // ~64 pixels per chunk
-  if (n > 64) n = 64;
-  if (n < 1) n = 1;
-  return n;
+  // >= 8 pixels per chunk, at most 128 chunks per image
+  int ppc = (P + 127) / 128;
+  if (ppc < 8) ppc = 8;
+  return (P + ppc - 1) / ppc;
 }
 
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
@@ -186,8 +207,8 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int ppc = (a.P + a.nchunk - 1) / a.nchunk;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(C8 * PY), 0, st, a, PY, ppc);
   SDMI_CHECK_HIP(hipGetLastError());
-  // apply: ~2048 items (8-channel chunks) per thread block iteration budget
-  int ppb = (256 * 8) / C8;
+  // apply: ~1024 items (8-channel chunks) per block = 4 per thread
+  int ppb = (256 * 4) / C8;
   if (ppb < 1) ppb = 1;
   const int nblk = (a.P + ppb - 1) / ppb;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a, ppb);

@@ -288,10 +288,11 @@ struct sdmi_unet {
     SDMI_CHECK_HIP(hipEventCreate(&e1));
     float best_us = 1e30f;
     const int nkt = a0.K / 64;
-    static const int kBM[] = {128, 128, 64, 64, 256, 128}, kBN[] = {128, 64, 128, 64, 128, 256};
     for (int cfg = 0; cfg < sdmi_gemm_num_cfgs(); ++cfg) {
-      if (a0.outT && (a0.nt0 % kBN[cfg]) != 0) continue;
-      const int tiles = ((a0.M + kBM[cfg] - 1) / kBM[cfg]) * ((a0.N + kBN[cfg] - 1) / kBN[cfg]);
+      int bm, bn;
+      sdmi_gemm_cfg_dims(cfg, &bm, &bn);
+      if (a0.outT && (a0.nt0 % bn) != 0) continue;
+      const int tiles = ((a0.M + bm - 1) / bm) * ((a0.N + bn - 1) / bn);
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
         if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
@@ -696,7 +697,7 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   if ((rc = u->dmalloc(&u->timevec_adhoc, (size_t)(u->time_total ? u->time_total : 1) * 4)) != SDMI_OK) return fail(rc);
   u->slab_bytes = (size_t)96 << 20;
   if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
-  if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 64 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
+  if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
   u->arena.cap = u->partial ? ((size_t)1 << 30) : ((size_t)6 << 30);
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) { sdmi_set_error("weight packing failed: %s", hipGetErrorString(hipGetLastError())); return fail(SDMI_EHIP); }
@@ -933,7 +934,7 @@ int sdmi_op_attention(const void* q, int ldq, const void* k, int ldk, int k_batc
 int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, const float* gamma,
                       const float* beta, float eps, int silu, void* y_f16, void* stream) {
   static float* partial = nullptr;
-  if (!partial) SDMI_CHECK_HIP(hipMalloc((void**)&partial, (size_t)64 * 64 * 32 * 2 * 4));
+  if (!partial) SDMI_CHECK_HIP(hipMalloc((void**)&partial, (size_t)64 * 128 * 32 * 2 * 4));
   SDMI_REQUIRE(B <= 64, "op_groupnorm: batch %d > 64", B);
   GnArgs g;
   memset(&g, 0, sizeof(g));
