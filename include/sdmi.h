@@ -120,6 +120,8 @@ typedef struct sdmi_gemm_desc {
   int cfg; int ksplit;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
+/* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
+int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);
 const char* sdmi_gemm_config_name(int cfg);
 

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "sdmi_unet_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
     "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sdmi_bench_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sdmi_gemm_num_configs": (C.c_int, []),
     "sdmi_gemm_config_name": (C.c_char_p, [C.c_int]),
     "sdmi_op_pack_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

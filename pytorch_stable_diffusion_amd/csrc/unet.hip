@@ -913,6 +913,25 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.zero = g_zero; a.slab = g_slab;
   return sdmi_launch_gemm(a, d->cfg, (hipStream_t)stream);
 }
+// Micro-benchmark: `iters` back-to-back launches bracketed by two HIP events on `stream`.
+int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream) {
+  if (!d || !us_per_iter || iters < 1) { sdmi_set_error("bench_gemm: bad arguments"); return SDMI_EINVAL; }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  SDMI_CHECK_HIP(hipEventCreate(&e0));
+  SDMI_CHECK_HIP(hipEventCreate(&e1));
+  TRY(sdmi_op_gemm(d, stream));
+  SDMI_CHECK_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) TRY(sdmi_op_gemm(d, stream));
+  SDMI_CHECK_HIP(hipEventRecord(e1, st));
+  SDMI_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SDMI_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_iter = ms * 1e3f / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return SDMI_OK;
+}
 int sdmi_gemm_num_configs(void) { return sdmi_gemm_num_cfgs(); }
 const char* sdmi_gemm_config_name(int cfg) { return sdmi_gemm_cfg_name(cfg); }
 

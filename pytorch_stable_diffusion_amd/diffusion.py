@@ -78,10 +78,9 @@ class Diffusion:
         return self._handle
 
     def set_context(self, context: torch.Tensor):
-        key = (context.data_ptr(), context._version, tuple(context.shape))
-        if key != self._ctx_key:
-            self.handle().set_context(context.to(self._device, torch.float32))
-            self._ctx_key = key
+        """Hoist the cross-attention K/V projections of ``context`` (B,77,768).  Always recomputed:
+        a pointer/version cache would be unsafe (the caching allocator reuses addresses)."""
+        self.handle().set_context(context.to(self._device, torch.float32))
 
     def set_schedule(self, time_embeddings: torch.Tensor):
         """time_embeddings: (n_steps, 320) rows of get_time_embedding(t)."""
