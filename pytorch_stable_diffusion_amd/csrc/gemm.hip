@@ -52,19 +52,38 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
+  // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+  // b+8 share an L2), so a plain map makes every XCD stream the whole activation tensor through its
+  // 4 MiB L2.  Remap (bijectively) so each XCD owns a CONTIGUOUS range of (k-split, m-tile, n-tile)
+  // ids: the 9 taps x n-tiles re-reads of an activation band then hit that XCD's L2.  Speed only.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tiles = tiles_n * ((p.M + BM - 1) / BM);
+  int kz, tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    kz = L / tiles;
+    tile = L - kz * tiles;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = p.K >> 6;
-  const int kt0 = blockIdx.y * p.ksteps_per;
+  const int kt0 = kz * p.ksteps_per;
   const int kt1 = min(kt0 + p.ksteps_per, nkt);
 
   const int Cin = p.C0 + p.C1;
   const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
 
-  // ---- per-lane staging descriptors -------------------------------------------------------
+  // ---- per-lane staging state --------------------------------------------------------------
+  // K is walked in SEGMENTS = (tap, concat source): inside a segment consecutive K-steps advance the
+  // per-row source pointer by 64 channels, so the im2col address is recomputed only at segment
+  // boundaries (every C_src/64 steps) and a K-step costs two 64-bit adds per staged row.
   int a_ihb[RA], a_iwb[RA], a_pix0[RA], a_gch[RA];
   bool a_ok[RA];
+  const f16* a_ptr[RA];
+  int a_inc[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int q = (i * NW + wave) * 64 + lane;
@@ -80,31 +99,31 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     a_pix0[i] = b * p.Hs * p.Ws;
   }
   const f16* b_ptr[RB];
-  bool b_ok[RB];
-  int b_gch[RB];
+  int b_inc[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int q = (i * NW + wave) * 64 + lane;
     const int row = q >> 3, pc = q & 7;
-    b_gch[i] = (pc ^ ((row >> 1) & 7)) * 8;
+    const int gch = (pc ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
-    b_ok[i] = n < p.N;
-    b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + (size_t)kt0 * 64 + b_gch[i];
+    const bool ok = n < p.N;
+    b_ptr[i] = ok ? p.w + (size_t)n * p.K + (size_t)kt0 * 64 + gch : p.zero + gch;
+    b_inc[i] = ok ? 64 : 0;
   }
 
-  // K-step -> (tap, ci0) tracked incrementally (wave-uniform)
+  // segment state (wave-uniform)
   int tap = (kt0 * 64) / Cin;
-  int ci0 = kt0 * 64 - tap * Cin;
+  int seg_c = kt0 * 64 - tap * Cin;       // channel offset inside the concatenated Cin
+  int seg_left = 0;                       // K-steps left in the current segment
 
-  auto stage = [&](int buf) {
-    char* sa = smem + buf * C::STAGE;
-    char* sb = sa + C::A_BYTES;
+  auto open_segment = [&]() {
     const int kh = (p.ks == 3) ? tap / 3 : 0;
     const int kw = (p.ks == 3) ? tap - kh * 3 : 0;
-    const bool second = ci0 >= p.C0;
+    const bool second = seg_c >= p.C0;
     const f16* base = second ? p.a1 : p.a0;
     const int cs = second ? p.C1 : p.C0;
-    const int cc = second ? ci0 - p.C0 : ci0;
+    const int cc = second ? seg_c - p.C0 : seg_c;
+    seg_left = (cs - cc) >> 6;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
@@ -112,18 +131,28 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       const int pix = a_pix0[i] + (ih >> p.ups) * p.Ws + (iw >> p.ups);
       const f16* gr = base + ((size_t)(unsigned)(pix * cs + cc) + a_gch[i]);
       const f16* gz = p.zero + a_gch[i];
-      const f16* g = v ? gr : gz;
-      glds16(g, sa + (i * NW + wave) * 1024);
+      a_ptr[i] = v ? gr : gz;
+      a_inc[i] = v ? 64 : 0;
+    }
+    seg_c += seg_left << 6;
+    if (seg_c >= Cin) { seg_c = 0; ++tap; }
+  };
+
+  auto stage = [&](int buf) {
+    char* sa = smem + buf * C::STAGE;
+    char* sb = sa + C::A_BYTES;
+    if (seg_left == 0) open_segment();
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      glds16(a_ptr[i], sa + (i * NW + wave) * 1024);
+      a_ptr[i] += a_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const f16* gz = p.zero + b_gch[i];
-      const f16* g = b_ok[i] ? b_ptr[i] : gz;
-      glds16(g, sb + (i * NW + wave) * 1024);
-      b_ptr[i] += 64;
+      glds16(b_ptr[i], sb + (i * NW + wave) * 1024);
+      b_ptr[i] += b_inc[i];
     }
-    ci0 += 64;
-    if (ci0 >= Cin) { ci0 = 0; ++tap; }
+    --seg_left;
   };
 
   // ---- fragment read offsets ---------------------------------------------------------------
@@ -199,7 +228,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   __syncthreads();
 
   if (p.ksplit > 1) {
-    float* slab = p.slab + (size_t)blockIdx.y * p.M * p.N;
+    float* slab = p.slab + (size_t)kz * p.M * p.N;
     for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
       const int row = idx / (BN / 4), c4 = idx % (BN / 4);
       const int m = m0 + row, n = n0 + c4 * 4;
@@ -399,7 +428,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     g_attr_done[cfg] = true;
   }
   const int tiles = ((a.M + c.BM - 1) / c.BM) * ((a.N + c.BN - 1) / c.BN);
-  hipLaunchKernelGGL(c.kern, dim3(tiles, p.ksplit), dim3(c.NT), c.LDS, st, p);
+  hipLaunchKernelGGL(c.kern, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
   SDMI_CHECK_HIP(hipGetLastError());
   if (p.ksplit > 1) {
     const size_t total8 = (size_t)p.M * (p.N / 8);
