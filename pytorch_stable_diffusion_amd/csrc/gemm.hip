@@ -20,9 +20,10 @@
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
+  static constexpr int STG = STG_;   // 0: LDS-DMA ring (global_load_lds); 1: register-staged double buffer
   static constexpr int NW = WM * WN, NT = 64 * NW;
   static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -172,13 +173,66 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- main loop: NS-deep LDS ring, loads stay in flight across barriers (counted vmcnt) --------
+  auto compute = [&](int buf) {
+    const char* As = smem + buf * C::STAGE + a_row_off;
+    const char* Bs = smem + buf * C::STAGE + C::A_BYTES + b_row_off;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f16x8 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(As + i * 32 * 128 + coff[s]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = kt1 - kt0;
+  if constexpr (C::STG == 1) {
+    // ---- register-staged double buffer: global_load -> VGPR issued one K-step ahead of its
+    //      ds_write_b128, which lands after the MFMAs of the current step (loads fly under the MFMAs).
+    f16x8 ra[RA], rb[RB];
+    auto load_regs = [&]() {
+      if (seg_left == 0) open_segment();
+#pragma unroll
+      for (int i = 0; i < RA; ++i) { ra[i] = *(const f16x8*)a_ptr[i]; a_ptr[i] += a_inc[i]; }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) { rb[i] = *(const f16x8*)b_ptr[i]; b_ptr[i] += b_inc[i]; }
+      --seg_left;
+    };
+    auto write_lds = [&](int buf) {
+      char* sa = smem + buf * C::STAGE;
+      char* sb = sa + C::A_BYTES;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) *(f16x8*)(sa + ((i * NW + wave) * 64 + lane) * 16) = ra[i];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *(f16x8*)(sb + ((i * NW + wave) * 64 + lane) * 16) = rb[i];
+    };
+    if (nk > 0) {
+      load_regs();
+      write_lds(0);
+      if (nk > 1) load_regs();
+      __syncthreads();
+      for (int t = 0; t < nk; ++t) {
+        compute(t & 1);
+        if (t + 1 < nk) {
+          write_lds((t + 1) & 1);
+          if (t + 2 < nk) load_regs();
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+  // ---- LDS-DMA ring: NS-deep, loads stay in flight across barriers (counted vmcnt) ---------------
   //   iteration t: wait until the loads of step t have landed (later groups may stay in flight),
   //   barrier (also closes the WAR window on the buffer read in iteration t-1), issue step t+NS-1
   //   into that buffer, then MFMA over buffer t % NS.
   constexpr int NS = C::NS;
   constexpr int G = RA + RB;              // LDS-DMA instructions per wave per stage
-  const int nk = kt1 - kt0;
   {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -191,26 +245,13 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < nk) stage(nxt);
-      const char* As = smem + cur * C::STAGE + a_row_off;
-      const char* Bs = smem + cur * C::STAGE + C::A_BYTES + b_row_off;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        f16x8 af[FM], bf[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(As + i * 32 * 128 + coff[s]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      compute(cur);
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, row-major [BM][BN]) -> coalesced global ----------
@@ -368,6 +409,8 @@ struct CfgInfo {
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
   {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
+#define CFG_ENTRY_R(BM, BN, WM, WN) \
+  {"t" #BM "x" #BN "r", BM, BN, 2, Cfg<BM, BN, WM, WN, 2, 1>::NT, Cfg<BM, BN, WM, WN, 2, 1>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, 2, 1>>}
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
     CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
@@ -375,6 +418,8 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY(64, 64, 2, 2, 2),   CFG_ENTRY(64, 64, 2, 2, 3),  CFG_ENTRY(64, 64, 2, 2, 4),
     CFG_ENTRY(256, 128, 4, 2, 2), CFG_ENTRY(256, 128, 4, 2, 3),
     CFG_ENTRY(128, 256, 2, 4, 2), CFG_ENTRY(128, 256, 2, 4, 3),
+    CFG_ENTRY_R(128, 128, 2, 2),  CFG_ENTRY_R(128, 64, 2, 2),  CFG_ENTRY_R(64, 128, 2, 2),
+    CFG_ENTRY_R(64, 64, 2, 2),    CFG_ENTRY_R(256, 128, 4, 2), CFG_ENTRY_R(128, 256, 2, 4),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};
