@@ -160,3 +160,100 @@ def n_params(manifest: Dict[str, Shape]) -> int:
             n *= s
         total += n
     return total
+
+
+# ---------------------------------------------------------------------------------------------
+# "Next rows" (SURVEY 8f): CLIP text encoder and VAE.  Same idea: the weight ABI is the
+# reference's state-dict key set (sd/model_converter.py:651-1008,1025-1054).
+# VAE stages are nn.Sequential positions (sd/encoder.py:8-94, sd/decoder.py:196-340):
+#   ("conv", cin, cout, ks, stride, pad) | ("res", cin, cout) | ("attn", c) | ("up",) | ("gn", c) | ("silu",)
+VAE_ENCODER = [
+    ("conv", 3, 128, 3, 1, 1), ("res", 128, 128), ("res", 128, 128),
+    ("conv", 128, 128, 3, 2, 0), ("res", 128, 256), ("res", 256, 256),
+    ("conv", 256, 256, 3, 2, 0), ("res", 256, 512), ("res", 512, 512),
+    ("conv", 512, 512, 3, 2, 0), ("res", 512, 512), ("res", 512, 512), ("res", 512, 512),
+    ("attn", 512), ("res", 512, 512), ("gn", 512), ("silu",),
+    ("conv", 512, 8, 3, 1, 1), ("conv", 8, 8, 1, 1, 0),
+]
+VAE_DECODER = [
+    ("conv", 4, 4, 1, 1, 0), ("conv", 4, 512, 3, 1, 1), ("res", 512, 512), ("attn", 512),
+    ("res", 512, 512), ("res", 512, 512), ("res", 512, 512), ("res", 512, 512),
+    ("up",), ("conv", 512, 512, 3, 1, 1), ("res", 512, 512), ("res", 512, 512), ("res", 512, 512),
+    ("up",), ("conv", 512, 512, 3, 1, 1), ("res", 512, 256), ("res", 256, 256), ("res", 256, 256),
+    ("up",), ("conv", 256, 256, 3, 1, 1), ("res", 256, 128), ("res", 128, 128), ("res", 128, 128),
+    ("gn", 128), ("silu",), ("conv", 128, 3, 3, 1, 1),
+]
+
+
+def _vae_manifest(stages):
+    m: "OrderedDict[str, Shape]" = OrderedDict()
+    norm_keys = set()
+    for i, op in enumerate(stages):
+        p = str(i)
+        if op[0] == "conv":
+            _, cin, cout, ks, _s, _p = op
+            m[f"{p}.weight"] = (cout, cin, ks, ks)
+            m[f"{p}.bias"] = (cout,)
+        elif op[0] == "res":
+            _, cin, cout = op
+            m[f"{p}.groupnorm_1.weight"] = (cin,)
+            m[f"{p}.groupnorm_1.bias"] = (cin,)
+            m[f"{p}.conv_1.weight"] = (cout, cin, 3, 3)
+            m[f"{p}.conv_1.bias"] = (cout,)
+            m[f"{p}.groupnorm_2.weight"] = (cout,)
+            m[f"{p}.groupnorm_2.bias"] = (cout,)
+            m[f"{p}.conv_2.weight"] = (cout, cout, 3, 3)
+            m[f"{p}.conv_2.bias"] = (cout,)
+            if cin != cout:
+                m[f"{p}.residual_layer.weight"] = (cout, cin, 1, 1)
+                m[f"{p}.residual_layer.bias"] = (cout,)
+        elif op[0] == "attn":
+            c = op[1]
+            m[f"{p}.groupnorm.weight"] = (c,)
+            m[f"{p}.groupnorm.bias"] = (c,)
+            m[f"{p}.attention.in_proj.weight"] = (3 * c, c)
+            m[f"{p}.attention.in_proj.bias"] = (3 * c,)
+            m[f"{p}.attention.out_proj.weight"] = (c, c)
+            m[f"{p}.attention.out_proj.bias"] = (c,)
+        elif op[0] == "gn":
+            m[f"{p}.weight"] = (op[1],)
+            m[f"{p}.bias"] = (op[1],)
+            norm_keys.update({f"{p}.weight", f"{p}.bias"})
+    return m, norm_keys
+
+
+def vae_encoder_manifest():
+    """({key: shape}, norm-parameter keys with positional names) of VAE_Encoder: 104 tensors."""
+    return _vae_manifest(VAE_ENCODER)
+
+
+def vae_decoder_manifest():
+    """Same for VAE_Decoder: 136 tensors, 49 490 199 parameters."""
+    return _vae_manifest(VAE_DECODER)
+
+
+CLIP_VOCAB, CLIP_DIM, CLIP_TOKENS, CLIP_LAYERS, CLIP_HEADS = 49408, 768, 77, 12, 12
+
+
+def clip_manifest() -> "OrderedDict[str, Shape]":
+    """CLIP text encoder (sd/clip.py:198-225): 148 tensors, 123 060 480 parameters."""
+    m: "OrderedDict[str, Shape]" = OrderedDict()
+    m["embedding.position_embedding"] = (CLIP_TOKENS, CLIP_DIM)
+    m["embedding.token_embedding.weight"] = (CLIP_VOCAB, CLIP_DIM)
+    for i in range(CLIP_LAYERS):
+        p = f"layers.{i}"
+        m[f"{p}.layernorm_1.weight"] = (CLIP_DIM,)
+        m[f"{p}.layernorm_1.bias"] = (CLIP_DIM,)
+        m[f"{p}.attention.in_proj.weight"] = (3 * CLIP_DIM, CLIP_DIM)
+        m[f"{p}.attention.in_proj.bias"] = (3 * CLIP_DIM,)
+        m[f"{p}.attention.out_proj.weight"] = (CLIP_DIM, CLIP_DIM)
+        m[f"{p}.attention.out_proj.bias"] = (CLIP_DIM,)
+        m[f"{p}.layernorm_2.weight"] = (CLIP_DIM,)
+        m[f"{p}.layernorm_2.bias"] = (CLIP_DIM,)
+        m[f"{p}.linear_1.weight"] = (4 * CLIP_DIM, CLIP_DIM)
+        m[f"{p}.linear_1.bias"] = (4 * CLIP_DIM,)
+        m[f"{p}.linear_2.weight"] = (CLIP_DIM, 4 * CLIP_DIM)
+        m[f"{p}.linear_2.bias"] = (CLIP_DIM,)
+    m["layernorm.weight"] = (CLIP_DIM,)
+    m["layernorm.bias"] = (CLIP_DIM,)
+    return m

@@ -87,12 +87,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   {
     const int g = tid & 31, sl = tid >> 5;
     float s = 0.f, q = 0.f;
-#pragma unroll 4
-    for (int ch = sl; ch < p.nchunk; ch += 8) {
-      const float* o = p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2;
-      s += o[0];
-      q += o[1];
+    // nchunk <= 128 -> at most 16 chunks per slice: all loads issued at once (one latency round)
+    f32x2 pv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ch = sl + 8 * k;
+      pv[k] = ch < p.nchunk ? *(const f32x2*)(p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s += pv[k][0]; q += pv[k][1]; }
     s_red[sl][g][0] = s;
     s_red[sl][g][1] = q;
   }

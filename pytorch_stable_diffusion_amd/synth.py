@@ -25,10 +25,12 @@ def _is_norm(key: str) -> bool:
 
 
 def synth_tensor(key: str, shape: Tuple[int, ...], fan_in: int | None = None,
-                 dtype=torch.float32) -> torch.Tensor:
+                 dtype=torch.float32, is_norm: bool | None = None, seed_key: str | None = None) -> torch.Tensor:
     g = torch.Generator(device="cpu")
-    g.manual_seed(_seed(key))
-    if _is_norm(key):
+    g.manual_seed(_seed(seed_key or key))
+    if key.endswith("position_embedding"):
+        return (torch.randn(shape, generator=g, dtype=torch.float32) * 0.02).to(dtype)
+    if _is_norm(key) if is_norm is None else is_norm:
         t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.1
         if key.endswith(".weight"):
             t += 1.0
@@ -44,18 +46,20 @@ def synth_tensor(key: str, shape: Tuple[int, ...], fan_in: int | None = None,
     return t.to(dtype)
 
 
-def synth_state_dict(manifest: Dict[str, Tuple[int, ...]], dtype=torch.float32
+def synth_state_dict(manifest: Dict[str, Tuple[int, ...]], dtype=torch.float32, norm_keys=(), seed_prefix: str = ""
                      ) -> "OrderedDict[str, torch.Tensor]":
-    """Generate every tensor of ``manifest``.  A bias takes the fan_in of the
-    ``.weight`` that shares its prefix."""
+    """Generate every tensor of ``manifest``.  A bias takes the fan_in of the ``.weight`` that shares
+    its prefix.  ``norm_keys``: norm parameters whose names do not say so (nn.Sequential positions);
+    ``seed_prefix`` disambiguates models whose keys collide (VAE encoder/decoder)."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for key, shape in manifest.items():
         fan_in = None
-        if len(shape) == 1 and not _is_norm(key):
+        norm = _is_norm(key) or key in norm_keys
+        if len(shape) == 1 and not norm:
             wkey = key.rsplit(".", 1)[0] + ".weight"
             wshape = manifest[wkey]
             fan_in = 1
             for s in wshape[1:]:
                 fan_in *= s
-        out[key] = synth_tensor(key, tuple(shape), fan_in, dtype)
+        out[key] = synth_tensor(key, tuple(shape), fan_in, dtype, is_norm=norm, seed_key=seed_prefix + key)
     return out

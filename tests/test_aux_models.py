@@ -1,0 +1,37 @@
+"""Interim CLIP / VAE modules vs golden vectors from the imported reference,
+on CPU (torch ops).  Pins the quirks Q3/Q4 and the in-place latent scaling."""
+import numpy as np
+import torch
+
+from pytorch_stable_diffusion_amd import model_loader
+from pytorch_stable_diffusion_amd.clip import CLIP
+from pytorch_stable_diffusion_amd.vae import VAE_Decoder, VAE_Encoder
+from tests import helpers as H
+
+
+def test_clip_vae_match_reference():
+    g = H.load_npz("aux.npz")
+    sds = model_loader.synthetic_state_dicts(("clip", "encoder", "decoder"))
+    c = CLIP()
+    c.load_state_dict(sds["clip"], strict=True)
+    out = c(torch.from_numpy(g["clip_tokens"]))
+    assert (out - torch.from_numpy(g["clip_out"])).abs().max().item() < 2e-5
+    d = VAE_Decoder()
+    d.load_state_dict(sds["decoder"], strict=True)
+    lat = H.seeded((1, 4, 8, 8), 301) * 0.18215 * 3
+    lat_in = lat.clone()
+    img = d(lat_in)
+    assert (img - torch.from_numpy(g["dec_out"])).abs().max().item() < 5e-5
+    assert abs(float((lat_in / lat).mean()) - float(g["dec_inplace_ratio"])) < 1e-5     # in-place /= 0.18215
+    e = VAE_Encoder()
+    e.load_state_dict(sds["encoder"], strict=True)
+    x = H.seeded((1, 3, 64, 64), 302).clamp(-1, 1)
+    z = e(x, H.seeded((1, 4, 8, 8), 303))
+    assert (z - torch.from_numpy(g["enc_out"])).abs().max().item() < 5e-5
+
+
+def test_strict_loading_errors():
+    import pytest
+    d = VAE_Decoder()
+    with pytest.raises(RuntimeError):
+        d.load_state_dict({"0.weight": torch.zeros(4, 4, 1, 1)}, strict=True)

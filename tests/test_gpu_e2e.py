@@ -1,0 +1,88 @@
+"""End-to-end drop-in check (-m gpu): this repo's pipeline.generate() on the GPU (native UNet loop +
+interim torch-ROCm CLIP/VAE) against the image the reference's own generate() produced on the CPU with the
+same synthetic weights, stub tokenizer, seed and prompt (tests/golden/e2e.npz).
+Stated tolerance (north_star): pixel MAE < 1e-3 on the [0,1] float image; uint8 images may differ by a few LSB."""
+import numpy as np
+import pytest
+import torch
+
+from tests import gpu_util as G
+from tests import helpers as H
+from tests.stub_tokenizer import StubTokenizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PIXEL_MAE = 1e-3
+
+
+class Tap:
+    def __init__(self, inner):
+        self.inner = inner
+        self.last = None
+
+    def to(self, d):
+        self.inner.to(d)
+        return self
+
+    def __call__(self, *a):
+        out = self.inner(*a)
+        self.last = out.clone()
+        return out
+
+
+@pytest.fixture(scope="module")
+def models():
+    from pytorch_stable_diffusion_amd import model_loader
+    m = model_loader.preload_models_synthetic(DEV)
+    m["decoder"] = Tap(m["decoder"])
+    return m
+
+
+def _check(name, img, float_img, g):
+    ref_u8 = g[f"{name}_u8"]
+    ref_f = torch.from_numpy(g[f"{name}_float"])
+    assert img.shape == ref_u8.shape == (512, 512, 3) and img.dtype == np.uint8
+    got_f = float_img[0, :, ::4, ::4].cpu()
+    mae = ((got_f - ref_f).abs().mean() / 2.0).item()          # decoder output is in [-1,1] -> /2 = [0,1] scale
+    du8 = np.abs(img.astype(np.int32) - ref_u8.astype(np.int32))
+    G.log_metric(test="e2e", name=name, pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()))
+    assert mae < PIXEL_MAE, f"{name}: pixel MAE {mae:.2e}"
+    assert du8.max() <= 8, f"{name}: uint8 max diff {du8.max()}"
+
+
+def test_txt2img_matches_reference_generate(models):
+    from pytorch_stable_diffusion_amd import pipeline
+    g = H.load_npz("e2e.npz")
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True,
+                            cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=20, models=models, seed=42,
+                            device=DEV, idle_device=None, tokenizer=StubTokenizer())
+    _check("txt2img", img, models["decoder"].last, g)
+
+
+def test_img2img_matches_reference_generate(models):
+    from PIL import Image
+    from pytorch_stable_diffusion_amd import pipeline
+    g = H.load_npz("e2e.npz")
+    dog = Image.fromarray(g["dog_u8"])
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=dog, strength=0.8, do_cfg=True,
+                            cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=10, models=models, seed=7,
+                            device=DEV, idle_device=None, tokenizer=StubTokenizer())
+    _check("img2img", img, models["decoder"].last, g)
+
+
+def test_generate_argument_errors(models):
+    from pytorch_stable_diffusion_amd import pipeline
+    with pytest.raises(ValueError):
+        pipeline.generate("a", "", strength=0.0, models=models, device=DEV, tokenizer=StubTokenizer())
+    with pytest.raises(ValueError):
+        pipeline.generate("a", "", sampler_name="euler", models=models, device=DEV, tokenizer=StubTokenizer(), n_inference_steps=2)
+    with pytest.raises(KeyError):
+        pipeline.generate("a", "", models={}, device=DEV, tokenizer=StubTokenizer())
+
+
+def test_768_generate_runs(models):
+    """BASELINE config 5 shape (96x96 latents): the loop and VAE run and return a 768x768 image."""
+    from pytorch_stable_diffusion_amd import pipeline
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, n_inference_steps=2,
+                            models=models, seed=1, device=DEV, tokenizer=StubTokenizer(), height=768, width=768)
+    assert img.shape == (768, 768, 3)
