@@ -409,6 +409,8 @@ struct CfgInfo {
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
   {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
+#define CFG_ENTRY_W(BM, BN, WM, WN, NS, TAG) \
+  {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
 #define CFG_ENTRY_R(BM, BN, WM, WN) \
   {"t" #BM "x" #BN "r", BM, BN, 2, Cfg<BM, BN, WM, WN, 2, 1>::NT, Cfg<BM, BN, WM, WN, 2, 1>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, 2, 1>>}
 const CfgInfo kCfgs[] = {
@@ -420,6 +422,11 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY(128, 256, 2, 4, 2), CFG_ENTRY(128, 256, 2, 4, 3),
     CFG_ENTRY_R(128, 128, 2, 2),  CFG_ENTRY_R(128, 64, 2, 2),  CFG_ENTRY_R(64, 128, 2, 2),
     CFG_ENTRY_R(64, 64, 2, 2),    CFG_ENTRY_R(256, 128, 4, 2), CFG_ENTRY_R(128, 256, 2, 4),
+    // 8/16-wave variants: two waves per SIMD so DMA issue / LDS latency of one hides under the other's MFMAs
+    CFG_ENTRY_W(128, 128, 2, 4, 2, "w8"), CFG_ENTRY_W(128, 128, 2, 4, 3, "w8"), CFG_ENTRY_W(128, 128, 4, 2, 3, "w8m"),
+    CFG_ENTRY_W(128, 64, 4, 2, 2, "w8"),  CFG_ENTRY_W(64, 128, 2, 4, 2, "w8"),
+    CFG_ENTRY_W(256, 128, 4, 4, 2, "w16"), CFG_ENTRY_W(256, 128, 4, 4, 3, "w16"),
+    CFG_ENTRY_W(128, 256, 4, 4, 2, "w16"),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};
