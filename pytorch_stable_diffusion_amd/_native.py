@@ -71,7 +71,8 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
 
 def lib_path() -> str:
-    return _build.LIB
+    """In-tree library; ``SDMI_LIB`` may point at another build of the same ABI (A/B benchmarking)."""
+    return os.environ.get("SDMI_LIB") or _build.LIB
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
@@ -80,7 +81,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if build_if_missing and _build.is_stale():
+    if build_if_missing and not os.environ.get("SDMI_LIB") and _build.is_stale():
         try:
             _build.build_native(verbose=False)
         except Exception as exc:  # no toolchain on this box and no prebuilt library

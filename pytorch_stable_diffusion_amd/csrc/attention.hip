@@ -15,6 +15,7 @@
 //   * the head-dim contraction is zero-padded on the Q fragment only (d=40 -> 48).
 //   * keys >= Skv are masked (cross-attention: 77 keys in a 128-key double tile).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,30 +54,48 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const f16* kbase = p.k + (size_t)b * p.k_batch_stride * p.ldk + head * D;
   const f16* vbase = p.vt + ((size_t)(b * p.H + head) * D) * p.ldvt;
 
-  auto stage = [&](int tile, int buf) {
+  // per-lane LDS-DMA source pointers, advanced by one 64-key tile per stage() call
+  constexpr int KI = (C::K_INST + 3) / 4, VI = C::V_INST / 4;
+  const f16* kptr[KI];
+  int krow[KI];
+  const f16* vptr[VI];
+  int vinc[VI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int q = (i * 4 + wave) * 64 + lane;
+    const int row = q / C::KCH, c = q - row * C::KCH;
+    krow[i] = row;
+    kptr[i] = kbase + (size_t)row * p.ldk + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < VI; ++i) {
+    const int q = (i * 4 + wave) * 64 + lane;
+    const int row = q >> 3, pc = q & 7;
+    const int gch = pc ^ ((row >> 1) & 7);
+    vptr[i] = row < D ? vbase + (size_t)row * p.ldvt + gch * 8 : p.zero + gch * 8;
+    vinc[i] = row < D ? 64 : 0;
+  }
+  const size_t kstep = (size_t)64 * p.ldk;
+  int stage_key0 = 0;
+
+  auto stage = [&](int buf) {
     char* sk = smem + buf * C::STAGE;
     char* sv = sk + C::K_BYTES;
-    const int key0 = tile * 64;
 #pragma unroll
-    for (int i = 0; i < (C::K_INST + 3) / 4; ++i) {
+    for (int i = 0; i < KI; ++i) {
       const int ii = i * 4 + wave;
       if (ii < C::K_INST) {
-        const int q = ii * 64 + lane;
-        const int row = q / C::KCH, c = q - row * C::KCH;
-        const int key = key0 + row;
-        const f16* g = key < p.Skv ? kbase + (size_t)key * p.ldk + c * 8 : p.zero + (c & 7) * 8;
+        const f16* g = stage_key0 + krow[i] < p.Skv ? kptr[i] : p.zero;
         glds16(g, sk + ii * 1024);
+        kptr[i] += kstep;
       }
     }
 #pragma unroll
-    for (int i = 0; i < C::V_INST / 4; ++i) {
-      const int ii = i * 4 + wave;
-      const int q = ii * 64 + lane;
-      const int row = q >> 3, pc = q & 7;
-      const int gch = pc ^ ((row >> 1) & 7);
-      const f16* g = row < D ? vbase + (size_t)row * p.ldvt + key0 + gch * 8 : p.zero + gch * 8;
-      glds16(g, sv + ii * 1024);
+    for (int i = 0; i < VI; ++i) {
+      glds16(vptr[i], sv + (i * 4 + wave) * 1024);
+      vptr[i] += vinc[i];
     }
+    stage_key0 += 64;
   };
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q = r, half h) holds dk = 16 s + 8 h + j ----
@@ -114,16 +133,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f;
   const float c = p.scale * 1.4426950408889634f;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T
+  auto tile_body = [&](auto masked_tag, int t, int cur) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const char* Ks = smem + cur * C::STAGE;
     const char* Vs = Ks + C::K_BYTES;
-
-    // ---- S^T tile: 64 keys x 32 queries ----
     f32x16 sacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -135,8 +149,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
     }
-    // mask keys beyond Skv (only possible in the last tile)
-    if (t == ntiles - 1 && (p.Skv & 63) != 0) {
+    if constexpr (MASKED) {   // keys beyond Skv (last, ragged tile only)
       const int kbase_i = t * 64 + 4 * h;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -146,33 +159,40 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           if (key >= p.Skv) sacc[kb][e] = -INFINITY;
         }
     }
-    // ---- online softmax (per query = per lane; the two half-waves hold disjoint keys) ----
-    float mx = sacc[0][0];
+    // online softmax (per query = per lane; the two half-waves hold disjoint keys).  Lazy rescale:
+    // the running max is raised (and O, l rescaled) only when some query's tile max exceeds it by
+    // more than 2^8 in the exp2 domain; otherwise P <= 256 (fine for fp16 P, fp32 l/O).  Wave-uniform.
+    float mx0 = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
+    float mx1 = fmaxf(fmaxf(sacc[1][0], sacc[1][1]), sacc[1][2]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
+    for (int e = 3; e < 15; e += 2) {
+      mx0 = fmaxf(fmaxf(mx0, sacc[0][e]), sacc[0][e + 1]);
+      mx1 = fmaxf(fmaxf(mx1, sacc[1][e]), sacc[1][e + 1]);
+    }
+    float mx = fmaxf(fmaxf(mx0, sacc[0][15]), fmaxf(mx1, sacc[1][15]));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float psum = 0.f;
+    if (__any((mx - m_run) * c > 8.f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int d = 0; d < C::DB; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[kb][e] * c - mc);
-        sacc[kb][e] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    const float mc = m_run * c;
+    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-    for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-
-    // ---- O^T += V^T P^T ----
+    for (int e = 0; e < 16; ++e) {
+      const float p0 = __builtin_amdgcn_exp2f(sacc[0][e] * c - mc);
+      const float p1 = __builtin_amdgcn_exp2f(sacc[1][e] * c - mc);
+      sacc[0][e] = p0;
+      sacc[1][e] = p1;
+      ps0 += p0;
+      ps1 += p1;
+    }
+    l_run += ps0 + ps1;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -194,10 +214,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
         }
       }
+  };
+
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bool ragged = (p.Skv & 63) != 0;
+  const int nfull = ragged ? ntiles - 1 : ntiles;
+  int cur = 0;
+  for (int t = 0; t < nfull; ++t) {
+    if (t + 1 < ntiles) stage(cur ^ 1);
+    tile_body(std::false_type{}, t, cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
+  if (ragged) tile_body(std::true_type{}, ntiles - 1, cur);
 
   // ---- normalise and store: lane = query row, registers = head-dim ----
   const float l_tot = l_run + __shfl_xor(l_run, 32);
