@@ -101,6 +101,17 @@ int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_c
 int sdmi_unet_last_launch_count(const sdmi_unet* u);
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);
 
+/* ---- VAE decoder (next row after the hot path; reference sd/decoder.py:342-374) ------------------
+ * tensors: the 136-entry state dict of VAE_Decoder (keys "0.weight" ... "25.bias",
+ * sd/model_converter.py:750-880,883-884,1028-1030).  latents_dev: (B,4,h,w) NCHW fp32 that the caller has
+ * already divided by 0.18215 (the reference does so in place, sd/decoder.py:364); image_dev: (B,3,8h,8w)
+ * NCHW fp32.  Reproduces the reference's VAE_AttentionBlock quirks (no groupnorm; reinterpreting view). */
+typedef struct sdmi_vae sdmi_vae;
+int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_vae** out);
+void sdmi_vae_destroy(sdmi_vae* v);
+int sdmi_vae_decode(sdmi_vae* v, const float* latents_dev, float* image_dev, int batch, int h, int w, void* stream);
+int sdmi_vae_last_launch_count(const sdmi_vae* v);
+
 /* ---- kernel-level entry points (parity tests / micro-benchmarks) ------------------------------ */
 
 /* Implicit-GEMM conv / linear:  out[m][n] = sum_k A(m,k) w[n][k] + bias[n] + res[m][n].

@@ -54,6 +54,10 @@ _SIGNATURES = {
     "sdmi_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "sdmi_unet_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
+    "sdmi_vae_decoder_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdmi_vae_destroy": (None, [C.c_void_p]),
+    "sdmi_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_vae_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sdmi_bench_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sdmi_gemm_num_configs": (C.c_int, []),
@@ -129,31 +133,72 @@ def _dtype_code(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported weight dtype {t.dtype} (need float32 or float16)")
 
 
+def _tensor_descs(state: Dict[str, torch.Tensor]):
+    if not state:
+        raise ValueError("empty state dict")
+    descs = (TensorDesc * len(state))()
+    keep = []
+    for i, (k, v) in enumerate(state.items()):
+        if not v.is_cuda:
+            raise ValueError(f"weight '{k}' is not on the GPU")
+        v = v.contiguous()
+        kb = k.encode()
+        keep += [v, kb]
+        descs[i].name = kb
+        descs[i].data_dev = v.data_ptr()
+        descs[i].dtype = _dtype_code(v)
+        descs[i].ndim = v.dim()
+        for j, s in enumerate(v.shape):
+            descs[i].shape[j] = s
+    return descs, keep
+
+
+class VaeDecoderHandle:
+    """Owns one native sdmi_vae (VAE decoder)."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], flags: int = FLAG_STREAM_F32):
+        lib = load()
+        descs, keep = _tensor_descs(state)
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(lib.sdmi_vae_decoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_decoder_create")
+        del keep
+        self._h, self._lib = h, lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdmi_vae_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, latents: torch.Tensor) -> torch.Tensor:
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.dim() == 4 and latents.shape[1] == 4
+        latents = latents.contiguous()
+        b, _, h, w = latents.shape
+        out = torch.empty((b, 3, 8 * h, 8 * w), dtype=torch.float32, device=latents.device)
+        check(self._lib.sdmi_vae_decode(self._h, ptr(latents), ptr(out), b, h, w, cur_stream()), "sdmi_vae_decode")
+        return out
+
+    @property
+    def last_launch_count(self) -> int:
+        return self._lib.sdmi_vae_last_launch_count(self._h)
+
+
 class UNetHandle:
     """Owns one native sdmi_unet.  ``state`` maps the reference's state-dict keys to CUDA tensors."""
 
     def __init__(self, state: Dict[str, torch.Tensor], flags: int = 0):
         lib = load()
-        if not state:
-            raise ValueError("empty state dict")
-        descs = (TensorDesc * len(state))()
-        keep = []
-        for i, (k, v) in enumerate(state.items()):
-            if not v.is_cuda:
-                raise ValueError(f"weight '{k}' is not on the GPU")
-            v = v.contiguous()
-            keep.append(v)
-            kb = k.encode()
-            keep.append(kb)
-            descs[i].name = kb
-            descs[i].data_dev = v.data_ptr()
-            descs[i].dtype = _dtype_code(v)
-            descs[i].ndim = v.dim()
-            for j, s in enumerate(v.shape):
-                descs[i].shape[j] = s
+        descs, keep = _tensor_descs(state)
         h = C.c_void_p()
         torch.cuda.synchronize()
         check(lib.sdmi_unet_create(descs, len(state), flags, C.byref(h)), "sdmi_unet_create")
+        del keep
         self._h = h
         self._lib = lib
         self.flags = flags

@@ -49,6 +49,8 @@ struct GemmArgs {
   const f16* a0;
   const f16* a1;       // second concat source or nullptr
   int C0, C1;          // channels per source (C1 = 0 when a1 == nullptr); multiples of 64
+  int lda0, lda1;      // pixel (row) stride of each source in elements; 0 = dense (= C0 / C1)
+  int ldw;             // row stride of w in elements; 0 = dense (= K)
   int Hs, Ws;          // stored source spatial dims
   int Ho, Wo;          // output spatial dims; M = B*Ho*Wo
   int ups;             // 1: nearest x2 upsample applied to the source on read
@@ -126,17 +128,22 @@ int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st);
 // misc kernels (misc.hip)
 int sdmi_launch_cast_f32_f16(const float* x, f16* y, size_t n, hipStream_t st);
 int sdmi_launch_pack_conv(const void* w, int w_f32, f16* out, int O, int I, int ks, int o_keep, hipStream_t st);
-int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, hipStream_t st);
+int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, int Cin, hipStream_t st);
 int sdmi_launch_cast_any_f32(const void* x, int in_f32, float* y, size_t n, hipStream_t st);
 // y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n]   (fp32 x/y, fp16 W), act = SiLU if silu
 int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float* y, int M, int N, int K,
                              int silu, int ldy, hipStream_t st);
 // stem conv 4->Cout from NCHW fp32 latents (batch-broadcast when lat_batch == 1)
 int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias,
-                          void* out, int out_f32, f16* out16, int B, int H, int W, int Cout, hipStream_t st);
+                          void* out, int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st);
 // final conv Cin->4 from NHWC fp16 (already GN+SiLU) to NCHW fp32
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W,
-                           int Cin, hipStream_t st);
+                           int Cin, int Cout, hipStream_t st);
+int sdmi_launch_row_softmax(const f16* s, f16* p, int rows, int L, float scale, hipStream_t st);
+int sdmi_launch_q4_reinterpret_add(const float* o, const void* x, int x_f32, void* y, int y_f32, f16* y16, int B, int P,
+                                   int C, hipStream_t st);
+int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* b, float* y, int B, int Cin, int Cout,
+                                   size_t HW, float in_scale, hipStream_t st);
 int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,
                          const float* coef, size_t n, float* eps_out, hipStream_t st);
 int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st);

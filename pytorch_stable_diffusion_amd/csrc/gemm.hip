@@ -108,7 +108,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const int gch = (pc ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
     const bool ok = n < p.N;
-    b_ptr[i] = ok ? p.w + (size_t)n * p.K + (size_t)kt0 * 64 + gch : p.zero + gch;
+    b_ptr[i] = ok ? p.w + (size_t)n * p.ldw + (size_t)kt0 * 64 + gch : p.zero + gch;
     b_inc[i] = ok ? 64 : 0;
   }
 
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const bool second = seg_c >= p.C0;
     const f16* base = second ? p.a1 : p.a0;
     const int cs = second ? p.C1 : p.C0;
+    const int ld = second ? p.lda1 : p.lda0;
     const int cc = second ? seg_c - p.C0 : seg_c;
     seg_left = (cs - cc) >> 6;
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       const int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
       const bool v = a_ok[i] && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
       const int pix = a_pix0[i] + (ih >> p.ups) * p.Ws + (iw >> p.ups);
-      const f16* gr = base + ((size_t)(unsigned)(pix * cs + cc) + a_gch[i]);
+      const f16* gr = base + ((size_t)pix * ld + cc + a_gch[i]);
       const f16* gz = p.zero + a_gch[i];
       a_ptr[i] = v ? gr : gz;
       a_inc[i] = v ? 64 : 0;
@@ -470,6 +471,10 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   }
   const int nkt = a.K / 64;
   GemmArgs p = a;
+  if (p.lda0 <= 0) p.lda0 = p.C0;
+  if (p.lda1 <= 0) p.lda1 = p.C1;
+  if (p.ldw <= 0) p.ldw = p.K;
+  SDMI_REQUIRE(p.lda0 % 8 == 0 && p.lda1 % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
   if (p.ksplit < 1) p.ksplit = 1;
   if (p.ksplit > nkt) p.ksplit = nkt;
   p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;

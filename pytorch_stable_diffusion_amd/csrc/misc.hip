@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const
 // w36: [36][Cout] fp32 with k = (kh*3+kw)*4 + ci.   thread = (pixel, 8 output channels)
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int lat_batch, const float* w36,
                                                         const float* bias, void* out, int out_f32, f16* out16,
-                                                        int B, int H, int W, int Cout) {
+                                                        int B, int H, int W, int Cout, int Cin) {
   const int C8 = Cout / 8;
   const size_t total = (size_t)B * H * W * C8;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -101,10 +101,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int la
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = ow + kw - 1;
         if ((unsigned)iw >= (unsigned)W) continue;
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-          const float xv = lat[(((size_t)lb * 4 + ci) * H + ih) * W + iw];
-          const float* wp = w36 + (size_t)((kh * 3 + kw) * 4 + ci) * Cout + c8 * 8;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = lat[(((size_t)lb * Cin + ci) * H + ih) * W + iw];
+          const float* wp = w36 + (size_t)((kh * 3 + kw) * Cin + ci) * Cout + c8 * 8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[e] += xv * wp[e];
         }
@@ -125,12 +124,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int la
   }
 }
 
-__global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout) {
-  const int total = 36 * Cout;
+__global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout, int Cin) {
+  const int total = 9 * Cin * Cout;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int co = idx % Cout, k = idx / Cout;
-    const int ci = k % 4, tap = k / 4, kh = tap / 3, kw = tap % 3;
-    const size_t src = (((size_t)co * 4 + ci) * 3 + kh) * 3 + kw;
+    const int ci = k % Cin, tap = k / Cin, kh = tap / 3, kw = tap % 3;
+    const size_t src = (((size_t)co * Cin + ci) * 3 + kh) * 3 + kw;
     w36[idx] = w_f32 ? ((const float*)w)[src] : (float)((const f16*)w)[src];
   }
 }
@@ -138,7 +137,7 @@ __global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout)
 // Output conv Cin -> 4, 3x3 s1 p1 (sd/diffusion.py:744) on the GN+SiLU'd NHWC fp16 tensor,
 // result NCHW fp32 (B,4,H,W).  One wave per output pixel; w packed [4][3][3][Cin] fp16.
 __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16* w, const float* bias, float* out,
-                                                         int B, int H, int W, int Cin) {
+                                                         int B, int H, int W, int Cin, int Cout) {
   const int lane = threadIdx.x & 63;
   const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t npix = (size_t)B * H * W;
@@ -157,9 +156,11 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
     const f16x8 xv = *(const f16x8*)(x + (((size_t)b * H + ih) * W + iw) * Cin + c8 * 8);
 #pragma unroll
     for (int co = 0; co < 4; ++co) {
-      const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
+      if (co < Cout) {
+        const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[co] += (float)xv[e] * (float)wv[e];
+        for (int e = 0; e < 8; ++e) acc[co] += (float)xv[e] * (float)wv[e];
+      }
     }
   }
 #pragma unroll
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
     for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
   if (lane == 0) {
 #pragma unroll
-    for (int co = 0; co < 4; ++co) out[(((size_t)b * 4 + co) * H + oh) * W + ow] = acc[co] + bias[co];
+    for (int co = 0; co < 4; ++co)
+      if (co < Cout) out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + bias[co];
   }
 }
 
@@ -209,6 +211,87 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* y, size_t 
     y[i] = a[i] + b[i];
 }
 
+
+// Row softmax over materialised scores (VAE single-head d=512 attention, sd/attention.py:55-76 via
+// sd/decoder.py:57): p = softmax(scale * s) per row, fp16 in / fp16 out, fp32 statistics.
+// One wave per row, row length L (multiple of 8).
+__global__ __launch_bounds__(256) void row_softmax_kernel(const f16* s, f16* p, int rows, int L, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* sp = s + (size_t)row * L;
+  f16* pp = p + (size_t)row * L;
+  const int L8 = L / 8;
+  float mx = -INFINITY;
+  for (int c8 = lane; c8 < L8; c8 += 64) {
+    const f16x8 v = *(const f16x8*)(sp + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float c = scale * 1.4426950408889634f, mc = mx * c;
+  float sum = 0.f;
+  for (int c8 = lane; c8 < L8; c8 += 64) {
+    const f16x8 v = *(const f16x8*)(sp + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((float)v[e] * c - mc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  for (int c8 = lane; c8 < L8; c8 += 64) {
+    const f16x8 v = *(const f16x8*)(sp + c8 * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)(__builtin_amdgcn_exp2f((float)v[e] * c - mc) * inv);
+    *(f16x8*)(pp + c8 * 8) = o;
+  }
+}
+
+// Quirk Q4 of the reference's VAE_AttentionBlock (sd/decoder.py:62,67): the (n, h*w, c) attention
+// output is REINTERPRETED as (n, c, h, w) by view() and added to the NCHW residual.  In NHWC storage:
+//   y[n][p][c] = o_flat[n][c*P + p] + x[n][p][c]        (P = h*w pixels, o fp32 [n][P*C])
+__global__ __launch_bounds__(256) void q4_reinterpret_add_kernel(const float* o, const void* x, int x_f32, void* y,
+                                                                 int y_f32, f16* y16, int B, int P, int C) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const float* on = o + (size_t)n * P * C;
+  for (int j = ty; j < 32; j += 8) {                             // read o as [C][P]: rows c, contiguous p
+    const int c = c0 + j, pp = p0 + tx;
+    tile[j][tx] = (c < C && pp < P) ? on[(size_t)c * P + pp] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {                             // write y as [P][C]: rows p, contiguous c
+    const int pp = p0 + j, c = c0 + tx;
+    if (pp < P && c < C) {
+      const size_t idx = ((size_t)n * P + pp) * C + c;
+      const float xv = x_f32 ? ((const float*)x)[idx] : (float)((const f16*)x)[idx];
+      const float v = tile[tx][j] + xv;
+      if (y_f32) { ((float*)y)[idx] = v; if (y16) y16[idx] = (f16)v; }
+      else ((f16*)y)[idx] = (f16)v;
+    }
+  }
+}
+
+// Tiny pointwise conv on NCHW fp32 (C <= 8 in and out): VAE decoder's first 1x1 conv 4->4
+// (sd/decoder.py:201) and the encoder's last 8->8 (sd/encoder.py:93).  in_scale multiplies the input.
+__global__ __launch_bounds__(256) void conv1x1_nchw_small_kernel(const float* x, const float* w, const float* b, float* y,
+                                                                 int B, int Cin, int Cout, size_t HW, float in_scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)B * HW; i += (size_t)gridDim.x * 256) {
+    const size_t n = i / HW, px = i - n * HW;
+    float v[8];
+    for (int ci = 0; ci < Cin; ++ci) v[ci] = x[(n * Cin + ci) * HW + px] * in_scale;
+    for (int co = 0; co < Cout; ++co) {
+      float acc = b[co];
+      for (int ci = 0; ci < Cin; ++ci) acc += w[co * Cin + ci] * v[ci];
+      y[(n * Cout + co) * HW + px] = acc;
+    }
+  }
+}
+
 inline int nblocks(size_t n, int per = 256, int cap = 4096) {
   size_t b = (n + per - 1) / per;
   if (b > (size_t)cap) b = cap;
@@ -237,8 +320,8 @@ int sdmi_launch_pack_conv(const void* w, int w_f32, f16* out, int O, int I, int 
   return SDMI_OK;
 }
 
-int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, hipStream_t st) {
-  hipLaunchKernelGGL(pack_stem_kernel, dim3(nblocks(36 * (size_t)Cout)), dim3(256), 0, st, w, w_f32, w36, Cout);
+int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, int Cin, hipStream_t st) {
+  hipLaunchKernelGGL(pack_stem_kernel, dim3(nblocks(9 * (size_t)Cin * Cout)), dim3(256), 0, st, w, w_f32, w36, Cout, Cin);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
@@ -256,20 +339,20 @@ int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float
 }
 
 int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias, void* out,
-                          int out_f32, f16* out16, int B, int H, int W, int Cout, hipStream_t st) {
-  SDMI_REQUIRE(Cout % 8 == 0, "stem conv: Cout=%d", Cout);
+                          int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st) {
+  SDMI_REQUIRE(Cout % 8 == 0 && Cin >= 1 && Cin <= 4, "stem conv: Cout=%d Cin=%d", Cout, Cin);
   const size_t total = (size_t)B * H * W * (Cout / 8);
   hipLaunchKernelGGL(stem_conv_kernel, dim3(nblocks(total)), dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32,
-                     out16, B, H, W, Cout);
+                     out16, B, H, W, Cout, Cin);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
 
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W, int Cin,
-                           hipStream_t st) {
-  SDMI_REQUIRE(Cin % 8 == 0, "final conv: Cin=%d", Cin);
+                           int Cout, hipStream_t st) {
+  SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "final conv: Cin=%d Cout=%d", Cin, Cout);
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin);
+  hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
@@ -291,6 +374,30 @@ int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* l
 
 int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(add_vec_kernel, dim3(nblocks(n)), dim3(256), 0, st, a, b, y, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_row_softmax(const f16* s, f16* p, int rows, int L, float scale, hipStream_t st) {
+  SDMI_REQUIRE(L % 8 == 0 && rows > 0, "row_softmax: rows=%d L=%d", rows, L);
+  hipLaunchKernelGGL(row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, s, p, rows, L, scale);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_q4_reinterpret_add(const float* o, const void* x, int x_f32, void* y, int y_f32, f16* y16, int B, int P,
+                                   int C, hipStream_t st) {
+  dim3 grid((P + 31) / 32, (C + 31) / 32, B);
+  hipLaunchKernelGGL(q4_reinterpret_add_kernel, grid, dim3(256), 0, st, o, x, x_f32, y, y_f32, y16, B, P, C);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* b, float* y, int B, int Cin, int Cout,
+                                   size_t HW, float in_scale, hipStream_t st) {
+  SDMI_REQUIRE(Cin <= 8 && Cout <= 8, "conv1x1_nchw_small: Cin=%d Cout=%d", Cin, Cout);
+  hipLaunchKernelGGL(conv1x1_nchw_small_kernel, dim3(nblocks((size_t)B * HW)), dim3(256), 0, st, x, w, b, y, B, Cin, Cout,
+                     HW, in_scale);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -5,18 +5,9 @@
 // activations (fp32 accumulation, optional fp32 residual stream): norms, implicit-GEMM convs/linears
 // with fused bias/time-vector/residual epilogues, flash attention.  Cross-attention K/V are hoisted
 // per prompt (set_context) and all timestep vectors per schedule (set_schedule).
-#include "common.h"
-#include "../../include/sdmi.h"
+#include "engine.h"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <tuple>
-#include <vector>
+using namespace sdmi;
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -26,478 +17,8 @@ void sdmi_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-int sdmi_launch_pack_stem(const void* w, int w_f32, float* w36, int Cout, hipStream_t st);
 
-#define TRY(expr)                  \
-  do {                             \
-    int _rc = (expr);              \
-    if (_rc != SDMI_OK) return _rc; \
-  } while (0)
-
-namespace {
-
-constexpr int kTime = 1280, kCtx = 768, kHeads = 8, kCtxPad = 80, kCtxVtLd = 128;
-
-struct ConvW { f16* w = nullptr; float* bias = nullptr; int O = 0, I = 0, ks = 0; };
-struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
-struct ResW {
-  NormW gn1, gn2;
-  ConvW conv1, conv2, skip;
-  ConvW time;             // linear_time [cout][1280]
-  float* bias1 = nullptr; // conv_feature.bias + linear_time.bias (time-independent part)
-  bool has_skip = false;
-  int cin = 0, cout = 0, time_off = 0;
-};
-struct AttnW {
-  NormW gn, ln1, ln2, ln3;
-  ConvW conv_in, conv_out, in_proj, out1, q, k, v, out2, g1, g2;
-  int C = 0, dh = 0, ctx_idx = 0;
-};
-struct Act {
-  f16* h = nullptr;
-  float* f = nullptr;
-  int B = 0, H = 0, W = 0, C = 0;
-  int M() const { return B * H * W; }
-};
-
-struct Arena {
-  char* base = nullptr;
-  size_t cap = 0, off = 0;
-  void* alloc(size_t bytes) {
-    const size_t a = (off + 255) & ~(size_t)255;
-    if (a + bytes > cap) return nullptr;
-    off = a + bytes;
-    return base + a;
-  }
-};
-
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;
-struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; };
-
-}  // namespace
-
-struct sdmi_unet {
-  int flags = 0;
-  bool stream_f32 = false, partial = false, tune = true;
-  std::vector<void*> owned;   // hipMalloc'd blocks
-  int64_t weight_bytes = 0;
-  std::map<std::string, sdmi_tensor_desc> src;
-  std::map<std::string, ResW> res;
-  std::map<std::string, AttnW> attn;
-  std::map<std::string, ConvW> convs;   // plain convs + upsample convs (3x3)
-  // time path
-  ConvW te1, te2;
-  bool has_time = false;
-  int time_total = 0;                  // sum of cout over residual blocks
-  std::vector<std::string> res_order;  // residual block prefixes in schedule order
-  float* timevec = nullptr;            // [n_steps][time_total]
-  int n_steps = 0;
-  float* timevec_adhoc = nullptr;      // [1][time_total]
-  float* time_scratch = nullptr;       // [max_steps][1280] x2
-  int max_steps = 0;
-  // stem / final
-  float* stem_w36 = nullptr; float* stem_bias = nullptr; int stem_cout = 0; bool has_stem = false;
-  NormW final_gn; ConvW final_conv; bool has_final = false;
-  // context
-  std::vector<std::string> attn_order;
-  f16* ctx16 = nullptr;                // [B][80][768]
-  std::vector<f16*> ctxK, ctxVt;       // per attention block: [B*80][C], [B][C][128]
-  int ctx_batch = 0, ctx_tokens = 0;
-  // scratch
-  f16* zero = nullptr;
-  Arena arena;
-  float* slab = nullptr; size_t slab_bytes = 0;
-  float* gn_partial = nullptr;
-  float* eps_buf = nullptr; size_t eps_elems = 0;
-  std::map<ShapeKey, Plan> plans;
-  int launches = 0;
-  hipStream_t st = nullptr;
-  // optional per-launch HIP-event profiling (bench roofline): class 0 = igemm, 1 = attention, 2 = other
-  bool profiling = false;
-  struct ProfRec { hipEvent_t e0, e1; int cls; double flops; };
-  std::vector<ProfRec> prof;
-  void prof_begin(int cls, double flops) {
-    if (!profiling) return;
-    ProfRec r; r.cls = cls; r.flops = flops;
-    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
-    (void)hipEventRecord(r.e0, st);
-    prof.push_back(r);
-  }
-  void prof_end() {
-    if (!profiling) return;
-    (void)hipEventRecord(prof.back().e1, st);
-  }
-
-  ~sdmi_unet() {
-    for (void* p : owned) (void)hipFree(p);
-  }
-
-  template <class T>
-  int dmalloc(T** out, size_t bytes) {
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
-      sdmi_set_error("hipMalloc(%zu) failed", bytes);
-      return SDMI_ENOMEM;
-    }
-    owned.push_back(p);
-    *out = (T*)p;
-    return SDMI_OK;
-  }
-
-  // ---- weight lookup / packing --------------------------------------------------------------
-  const sdmi_tensor_desc* find(const std::string& name) const {
-    auto it = src.find(name);
-    return it == src.end() ? nullptr : &it->second;
-  }
-  bool has(const std::string& name) const { return src.count(name) != 0; }
-
-  int need(const std::string& name, const sdmi_tensor_desc** out, int ndim, std::initializer_list<int64_t> shape) {
-    const sdmi_tensor_desc* t = find(name);
-    if (!t) { sdmi_set_error("missing tensor '%s'", name.c_str()); return SDMI_ENOENT; }
-    if (t->ndim != ndim) { sdmi_set_error("tensor '%s': ndim %d, expected %d", name.c_str(), t->ndim, ndim); return SDMI_EINVAL; }
-    int i = 0;
-    for (int64_t s : shape) {
-      if (s >= 0 && t->shape[i] != s) {
-        sdmi_set_error("tensor '%s': dim %d is %lld, expected %lld", name.c_str(), i, (long long)t->shape[i], (long long)s);
-        return SDMI_EINVAL;
-      }
-      ++i;
-    }
-    *out = t;
-    return SDMI_OK;
-  }
-
-  int load_vec(const std::string& name, int n, float** out) {
-    const sdmi_tensor_desc* t;
-    TRY(need(name, &t, 1, {n}));
-    TRY(dmalloc(out, (size_t)n * 4));
-    TRY(sdmi_launch_cast_any_f32(t->data_dev, t->dtype == SDMI_F32, *out, n, st));
-    weight_bytes += (int64_t)n * 4;
-    return SDMI_OK;
-  }
-  int load_norm(const std::string& p, int C, NormW* w) {
-    w->C = C;
-    TRY(load_vec(p + ".weight", C, &w->gamma));
-    TRY(load_vec(p + ".bias", C, &w->beta));
-    return SDMI_OK;
-  }
-  // conv (ks=3/1, 4-D weight) or linear (2-D weight); o_keep < O keeps only the first rows
-  int load_conv(const std::string& p, int O, int I, int ks, bool bias, ConvW* w, int o_keep = -1) {
-    if (o_keep < 0) o_keep = O;
-    const sdmi_tensor_desc* t;
-    if (find(p + ".weight") && find(p + ".weight")->ndim == 2) TRY(need(p + ".weight", &t, 2, {O, (int64_t)I * ks * ks}));
-    else TRY(need(p + ".weight", &t, 4, {O, I, ks, ks}));
-    w->O = o_keep; w->I = I; w->ks = ks;
-    const size_t n = (size_t)o_keep * ks * ks * I;
-    TRY(dmalloc(&w->w, n * 2));
-    TRY(sdmi_launch_pack_conv(t->data_dev, t->dtype == SDMI_F32, w->w, O, I, ks, o_keep, st));
-    weight_bytes += (int64_t)n * 2;
-    if (bias) {
-      const sdmi_tensor_desc* b;
-      TRY(need(p + ".bias", &b, 1, {O}));
-      TRY(dmalloc(&w->bias, (size_t)o_keep * 4));
-      TRY(sdmi_launch_cast_any_f32(b->data_dev, b->dtype == SDMI_F32, w->bias, o_keep, st));
-      weight_bytes += (int64_t)o_keep * 4;
-    }
-    return SDMI_OK;
-  }
-
-  int load_res(const std::string& p, int cin, int cout) {
-    ResW r;
-    r.cin = cin; r.cout = cout;
-    TRY(load_norm(p + ".groupnorm_feature", cin, &r.gn1));
-    TRY(load_conv(p + ".conv_feature", cout, cin, 3, true, &r.conv1));
-    TRY(load_conv(p + ".linear_time", cout, kTime, 1, true, &r.time));
-    TRY(load_norm(p + ".groupnorm_merged", cout, &r.gn2));
-    TRY(load_conv(p + ".conv_merged", cout, cout, 3, true, &r.conv2));
-    r.has_skip = cin != cout;
-    if (r.has_skip) TRY(load_conv(p + ".residual_layer", cout, cin, 1, true, &r.skip));
-    TRY(dmalloc(&r.bias1, (size_t)cout * 4));
-    TRY(sdmi_launch_add_vec(r.conv1.bias, r.time.bias, r.bias1, cout, st));
-    r.time_off = time_total;
-    time_total += cout;
-    res[p] = r;
-    res_order.push_back(p);
-    return SDMI_OK;
-  }
-  int load_attn(const std::string& p, int heads, int dh) {
-    AttnW a;
-    const int C = heads * dh;
-    a.C = C; a.dh = dh;
-    TRY(load_norm(p + ".groupnorm", C, &a.gn));
-    TRY(load_conv(p + ".conv_input", C, C, 1, true, &a.conv_in));
-    TRY(load_norm(p + ".layernorm_1", C, &a.ln1));
-    TRY(load_conv(p + ".attention_1.in_proj", 3 * C, C, 1, false, &a.in_proj));
-    TRY(load_conv(p + ".attention_1.out_proj", C, C, 1, true, &a.out1));
-    TRY(load_norm(p + ".layernorm_2", C, &a.ln2));
-    TRY(load_conv(p + ".attention_2.q_proj", C, C, 1, false, &a.q));
-    TRY(load_conv(p + ".attention_2.k_proj", C, kCtx, 1, false, &a.k));
-    TRY(load_conv(p + ".attention_2.v_proj", C, kCtx, 1, false, &a.v));
-    TRY(load_conv(p + ".attention_2.out_proj", C, C, 1, true, &a.out2));
-    TRY(load_norm(p + ".layernorm_3", C, &a.ln3));
-    // quirk Q2 (sd/diffusion.py:359-363): only the first 4C output rows of linear_geglu_1 are live
-    TRY(load_conv(p + ".linear_geglu_1", 8 * C, C, 1, true, &a.g1, 4 * C));
-    TRY(load_conv(p + ".linear_geglu_2", C, 4 * C, 1, true, &a.g2));
-    TRY(load_conv(p + ".conv_output", C, C, 1, true, &a.conv_out));
-    a.ctx_idx = (int)attn_order.size();
-    attn[p] = a;
-    attn_order.push_back(p);
-    return SDMI_OK;
-  }
-  int load_plain_conv(const std::string& p, int cin, int cout) {
-    ConvW c;
-    TRY(load_conv(p, cout, cin, 3, true, &c));
-    convs[p] = c;
-    return SDMI_OK;
-  }
-
-  // ---- activations ---------------------------------------------------------------------------
-  int new_act(int B, int H, int W, int C, bool is_stream, Act* a) {
-    a->B = B; a->H = H; a->W = W; a->C = C;
-    const size_t n = (size_t)B * H * W * C;
-    a->h = (f16*)arena.alloc(n * 2);
-    a->f = nullptr;
-    if (is_stream && stream_f32) a->f = (float*)arena.alloc(n * 4);
-    if (!a->h || (is_stream && stream_f32 && !a->f)) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
-    return SDMI_OK;
-  }
-
-  // ---- GEMM with per-shape plan -----------------------------------------------------------------
-  int gemm(GemmArgs a) {
-    a.zero = zero;
-    a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks, a.stride, a.ups, a.C0, a.C1, a.Wo, a.outT ? a.nt0 + 1 : 0);
-    auto it = plans.find(key);
-    if (it == plans.end()) {
-      Plan pl;
-      if (tune) TRY(tune_gemm(a, &pl));
-      it = plans.emplace(key, pl).first;
-    }
-    a.ksplit = it->second.ksplit;
-    const int nl = a.ksplit > 1 ? 2 : 1;
-    prof_begin(0, 2.0 * a.M * a.N * a.K);
-    TRY(sdmi_launch_gemm(a, it->second.cfg, st));
-    prof_end();
-    launches += nl;
-    return SDMI_OK;
-  }
-
-  int tune_gemm(const GemmArgs& a0, Plan* best) {
-    hipEvent_t e0, e1;
-    SDMI_CHECK_HIP(hipEventCreate(&e0));
-    SDMI_CHECK_HIP(hipEventCreate(&e1));
-    float best_us = 1e30f;
-    const int nkt = a0.K / 64;
-    for (int cfg = 0; cfg < sdmi_gemm_num_cfgs(); ++cfg) {
-      int bm, bn;
-      sdmi_gemm_cfg_dims(cfg, &bm, &bn);
-      if (a0.outT && (a0.nt0 % bn) != 0) continue;
-      const int tiles = ((a0.M + bm - 1) / bm) * ((a0.N + bn - 1) / bn);
-      for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
-        if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
-        if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
-        GemmArgs a = a0;
-        a.ksplit = ks;
-        float us = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
-          SDMI_CHECK_HIP(hipEventRecord(e0, st));
-          int rc = sdmi_launch_gemm(a, cfg, st);
-          if (rc != SDMI_OK) return rc;
-          SDMI_CHECK_HIP(hipEventRecord(e1, st));
-          SDMI_CHECK_HIP(hipEventSynchronize(e1));
-          float ms = 0.f;
-          SDMI_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-          if (rep > 0 && ms * 1e3f < us) us = ms * 1e3f;
-        }
-        if (us < best_us) { best_us = us; best->cfg = cfg; best->ksplit = ks; best->us = us; }
-      }
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (getenv("SDMI_TUNE_LOG"))
-      fprintf(stderr, "[sdmi tune] M=%d N=%d K=%d ks=%d s=%d up=%d -> %s split %d  %.1f us  (%.1f TF/s)\n", a0.M, a0.N,
-              a0.K, a0.ks, a0.stride, a0.ups, sdmi_gemm_cfg_name(best->cfg), best->ksplit, best->us,
-              2.0 * a0.M * a0.N * a0.K / best->us * 1e-6);
-    return SDMI_OK;
-  }
-
-  static GemmArgs base_args(const Act& x, const Act* x1, const ConvW& w, int Ho, int Wo, int stride, int ups) {
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.a0 = x.h; a.C0 = x.C;
-    if (x1) { a.a1 = x1->h; a.C1 = x1->C; }
-    a.Hs = x.H; a.Ws = x.W; a.Ho = Ho; a.Wo = Wo;
-    a.ups = ups; a.stride = stride; a.ks = w.ks; a.pad = w.ks == 3 ? 1 : 0;
-    a.M = x.B * Ho * Wo; a.N = w.O; a.K = w.ks * w.ks * (a.C0 + a.C1);
-    a.w = w.w; a.bias = w.bias;
-    a.ksplit = 1;
-    return a;
-  }
-  void set_out(GemmArgs& a, const Act& y) const {
-    if (y.f) { a.out = y.f; a.out_f32 = 1; a.out16 = y.h; }
-    else { a.out = y.h; a.out_f32 = 0; a.out16 = nullptr; }
-    a.ldc = y.C;
-  }
-  static void set_res(GemmArgs& a, const Act& r) {
-    if (r.f) { a.res = r.f; a.res_f32 = 1; } else { a.res = r.h; a.res_f32 = 0; }
-    a.ldr = r.C;
-  }
-
-  int groupnorm(const Act& x, const Act* x1, const NormW& w, float eps, int silu, Act* y) {
-    const int C = x.C + (x1 ? x1->C : 0);
-    if (w.C != C) { sdmi_set_error("groupnorm: weight C=%d vs input C=%d", w.C, C); return SDMI_EINVAL; }
-    TRY(new_act(x.B, x.H, x.W, C, false, y));
-    GnArgs g;
-    memset(&g, 0, sizeof(g));
-    const bool f32 = x.f != nullptr;
-    g.x0 = f32 ? (const void*)x.f : (const void*)x.h;
-    if (x1) g.x1 = f32 ? (const void*)x1->f : (const void*)x1->h;
-    g.in_f32 = f32; g.C0 = x.C; g.C1 = x1 ? x1->C : 0;
-    g.B = x.B; g.P = x.H * x.W;
-    g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
-    g.y = y->h; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
-    prof_begin(2, 0.0);
-    TRY(sdmi_launch_groupnorm(g, st));
-    prof_end();
-    launches += 2;
-    return SDMI_OK;
-  }
-  int layernorm(const Act& x, const NormW& w, Act* y) {
-    TRY(new_act(x.B, x.H, x.W, x.C, false, y));
-    LnArgs l;
-    memset(&l, 0, sizeof(l));
-    l.x = x.f ? (const void*)x.f : (const void*)x.h;
-    l.in_f32 = x.f != nullptr;
-    l.M = x.M(); l.C = x.C; l.gamma = w.gamma; l.beta = w.beta; l.eps = 1e-5f; l.y = y->h;
-    prof_begin(2, 0.0);
-    TRY(sdmi_launch_layernorm(l, st));
-    prof_end();
-    launches += 1;
-    return SDMI_OK;
-  }
-
-  // ---- blocks -------------------------------------------------------------------------------
-  // UNET_ResidualBlock (sd/diffusion.py:145-209).  bias1 = conv_feature.bias + linear_time(silu(time))
-  int res_block(const ResW& r, const Act& x, const Act* x1, const float* bias1, Act* y) {
-    const int cin = x.C + (x1 ? x1->C : 0);
-    if (cin != r.cin) { sdmi_set_error("res_block: cin %d vs %d", cin, r.cin); return SDMI_EINVAL; }
-    Act t0, h, t1, sk;
-    TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
-    TRY(new_act(x.B, x.H, x.W, r.cout, false, &h));
-    {
-      GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
-      a.bias = bias1;
-      a.out = h.h; a.ldc = h.C;
-      TRY(gemm(a));
-    }
-    TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
-    TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
-    GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
-    if (r.has_skip) {
-      TRY(new_act(x.B, x.H, x.W, r.cout, true, &sk));
-      GemmArgs s = base_args(x, x1, r.skip, x.H, x.W, 1, 0);
-      if (sk.f) { s.out = sk.f; s.out_f32 = 1; } else { s.out = sk.h; }
-      s.ldc = sk.C;
-      TRY(gemm(s));
-      set_res(a, sk);
-    } else {
-      set_res(a, x);
-    }
-    set_out(a, *y);
-    TRY(gemm(a));
-    return SDMI_OK;
-  }
-
-  int attention(const f16* q, int ldq, const f16* k, int ldk, int kbs, const f16* vt, int ldvt, f16* o, int ldo, int B,
-                int d, int Sq, int Skv) {
-    AttnArgs t;
-    memset(&t, 0, sizeof(t));
-    t.q = q; t.ldq = ldq; t.k = k; t.ldk = ldk; t.k_batch_stride = kbs; t.vt = vt; t.ldvt = ldvt;
-    t.o = o; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero;
-    t.scale = 1.f / sqrtf((float)d);
-    prof_begin(1, 4.0 * B * kHeads * (double)Sq * Skv * d);
-    TRY(sdmi_launch_attention(t, st));
-    prof_end();
-    launches += 1;
-    return SDMI_OK;
-  }
-
-  // UNET_AttentionBlock (sd/diffusion.py:271-381)
-  int attn_block(const AttnW& w, const Act& x, Act* y) {
-    if (x.C != w.C) { sdmi_set_error("attn_block: C %d vs %d", x.C, w.C); return SDMI_EINVAL; }
-    if (ctx_batch != x.B || (int)ctxK.size() <= w.ctx_idx) {
-      sdmi_set_error("attn_block: context not set for batch %d (sdmi_unet_set_context)", x.B);
-      return SDMI_EINVAL;
-    }
-    const int B = x.B, S = x.H * x.W, C = w.C, M = x.M();
-    const int Spad = ((S + 63) / 64) * 64;
-    Act t0, s0, u, qk, ao, s1, q2, s2, g, s3;
-    TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
-    TRY(new_act(B, x.H, x.W, C, true, &s0));
-    { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a)); }
-    // self-attention
-    TRY(layernorm(s0, w.ln1, &u));
-    TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
-    f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
-    if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
-    if (Spad != S) { SDMI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)B * C * Spad * 2, st)); launches += 1; }
-    {
-      GemmArgs a = base_args(u, nullptr, w.in_proj, x.H, x.W, 1, 0);
-      a.out = qk.h; a.ldc = 2 * C;
-      a.outT = vt; a.nt0 = 2 * C; a.S = S; a.ldt = Spad;
-      TRY(gemm(a));
-    }
-    TRY(new_act(B, x.H, x.W, C, false, &ao));
-    TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
-    TRY(new_act(B, x.H, x.W, C, true, &s1));
-    { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a)); }
-    // cross-attention (K/V hoisted in set_context)
-    TRY(layernorm(s1, w.ln2, &u));
-    TRY(new_act(B, x.H, x.W, C, false, &q2));
-    { GemmArgs a = base_args(u, nullptr, w.q, x.H, x.W, 1, 0); a.out = q2.h; a.ldc = C; TRY(gemm(a)); }
-    TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
-    TRY(new_act(B, x.H, x.W, C, true, &s2));
-    { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a)); }
-    // feed-forward: first half of linear_geglu_1 only (reference discards the gate)
-    TRY(layernorm(s2, w.ln3, &u));
-    TRY(new_act(B, x.H, x.W, 4 * C, false, &g));
-    { GemmArgs a = base_args(u, nullptr, w.g1, x.H, x.W, 1, 0); a.out = g.h; a.ldc = 4 * C; TRY(gemm(a)); }
-    TRY(new_act(B, x.H, x.W, C, true, &s3));
-    { GemmArgs a = base_args(g, nullptr, w.g2, x.H, x.W, 1, 0); set_res(a, s2); set_out(a, s3); TRY(gemm(a)); }
-    TRY(new_act(B, x.H, x.W, C, true, y));
-    { GemmArgs a = base_args(s3, nullptr, w.conv_out, x.H, x.W, 1, 0); set_res(a, x); set_out(a, *y); TRY(gemm(a)); }
-    return SDMI_OK;
-  }
-
-  int conv3(const ConvW& w, const Act& x, int stride, int ups, Act* y) {
-    const int Hi = x.H << ups, Wi = x.W << ups;
-    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    TRY(new_act(x.B, Ho, Wo, w.O, true, y));
-    GemmArgs a = base_args(x, nullptr, w, Ho, Wo, stride, ups);
-    set_out(a, *y);
-    TRY(gemm(a));
-    return SDMI_OK;
-  }
-
-  // ---- time path ----------------------------------------------------------------------------
-  int compute_timevecs(const float* temb, int n, float* out_rows) {
-    if (!has_time) { sdmi_set_error("time embedding weights not loaded"); return SDMI_ENOENT; }
-    if (n > max_steps) { sdmi_set_error("schedule of %d steps exceeds max %d", n, max_steps); return SDMI_EINVAL; }
-    float* t1 = time_scratch;
-    float* t2 = time_scratch + (size_t)max_steps * kTime;
-    TRY(sdmi_launch_small_linear(temb, te1.w, te1.bias, t1, n, kTime, 320, 0, kTime, st));
-    TRY(sdmi_launch_small_linear(t1, te2.w, te2.bias, t2, n, kTime, kTime, 1, kTime, st));
-    for (const std::string& p : res_order) {
-      const ResW& r = res[p];
-      TRY(sdmi_launch_small_linear(t2, r.time.w, r.bias1, out_rows + r.time_off, n, r.cout, kTime, 1, time_total, st));
-    }
-    return SDMI_OK;
-  }
-  // time_dev: (1,1280) TimeEmbedding output given directly (block tests)
-  int compute_timevec_from_time(const float* time_dev, const ResW& r, float* out) {
-    return sdmi_launch_small_linear(time_dev, r.time.w, r.bias1, out, 1, r.cout, kTime, 1, r.cout, st);
-  }
-};
+struct sdmi_unet : Engine {};
 
 // =============================================================================================
 namespace {
@@ -561,7 +82,7 @@ int load_op(sdmi_unet* u, const std::string& p, const StageOp& op, bool lenient)
         const sdmi_tensor_desc* t;
         TRY(u->need(p + ".weight", &t, 4, {op.b, 4, 3, 3}));
         TRY(u->dmalloc(&u->stem_w36, (size_t)36 * op.b * 4));
-        TRY(sdmi_launch_pack_stem(t->data_dev, t->dtype == SDMI_F32, u->stem_w36, op.b, u->st));
+        TRY(sdmi_launch_pack_stem(t->data_dev, t->dtype == SDMI_F32, u->stem_w36, op.b, 4, u->st));
         TRY(u->load_vec(p + ".bias", op.b, &u->stem_bias));
         u->stem_cout = op.b;
         u->has_stem = true;
@@ -627,7 +148,7 @@ int final_layer(sdmi_unet* u, const Act& x, float* eps_out) {
   if (!u->has_final) { sdmi_set_error("final layer not loaded"); return SDMI_ENOENT; }
   Act t;
   TRY(u->groupnorm(x, nullptr, u->final_gn, 1e-5f, 1, &t));
-  TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, u->st));
+  TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, 4, u->st));
   u->launches += 1;
   return SDMI_OK;
 }
@@ -737,9 +258,9 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
   c.h = u->ctx16; c.B = batch; c.H = kCtxPad; c.W = 1; c.C = kCtx;
   for (size_t i = 0; i < u->attn_order.size(); ++i) {
     const AttnW& w = u->attn[u->attn_order[i]];
-    { GemmArgs a = sdmi_unet::base_args(c, nullptr, w.k, kCtxPad, 1, 1, 0); a.out = u->ctxK[i]; a.ldc = w.C; TRY(u->gemm(a)); }
+    { GemmArgs a = Engine::base_args(c, nullptr, w.k, kCtxPad, 1, 1, 0); a.out = u->ctxK[i]; a.ldc = w.C; TRY(u->gemm(a)); }
     {
-      GemmArgs a = sdmi_unet::base_args(c, nullptr, w.v, kCtxPad, 1, 1, 0);
+      GemmArgs a = Engine::base_args(c, nullptr, w.v, kCtxPad, 1, 1, 0);
       a.out = u->ctxK[i];   // unused (all columns go to the transposed tail)
       a.ldc = w.C;
       a.outT = u->ctxVt[i]; a.nt0 = 0; a.S = kCtxPad; a.ldt = kCtxVtLd;
@@ -778,7 +299,7 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
   Act x;
   TRY(u->new_act(batch, h, w, u->stem_cout, true, &x));
   TRY(sdmi_launch_stem_conv(latents_dev, latent_batch, u->stem_w36, u->stem_bias, x.f ? (void*)x.f : (void*)x.h,
-                            x.f != nullptr, x.f ? x.h : nullptr, batch, h, w, u->stem_cout, u->st));
+                            x.f != nullptr, x.f ? x.h : nullptr, batch, h, w, u->stem_cout, 4, u->st));
   u->launches += 1;
   std::vector<Act> skips;
   skips.push_back(x);

@@ -104,14 +104,51 @@ def _run(sd, stages, x, pad_stride2: bool):
 
 
 class VAE_Decoder(_StateModule):
-    def __init__(self):
+    """``backend="native"`` (default): hand-written HIP kernels through libsdmi (csrc/vae.hip); needs a
+    cuda device, no fallback.  ``backend="torch"``: explicit opt-in to the PyTorch-op restatement (used by
+    CPU unit tests of the quirk semantics and as an A/B reference on the GPU)."""
+
+    def __init__(self, backend: str = "native"):
         super().__init__(arch.vae_decoder_manifest()[0])
+        if backend not in ("native", "torch"):
+            raise ValueError(f"unknown backend {backend}")
+        self.backend = backend
+        self._handle = None
+
+    def load_state_dict(self, state, strict: bool = True):
+        super().load_state_dict(state, strict)
+        self._drop()
+        return self
+
+    def to(self, device):
+        before = self._device
+        super().to(device)
+        if self._device != before:
+            self._drop()
+        return self
+
+    def _drop(self):
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = None
+
+    def handle(self):
+        from . import _native
+        if self._handle is None:
+            if self._device.type != "cuda":
+                raise RuntimeError("VAE_Decoder(backend='native') needs a cuda (ROCm) device; there is no CPU fallback "
+                                   "(use backend='torch' explicitly for a PyTorch-op restatement)")
+            with torch.cuda.device(self._device):
+                self._handle = _native.VaeDecoderHandle(self._state)
+        return self._handle
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         """(B,4,h,w) -> (B,3,8h,8w); divides the caller's tensor by 0.18215 in place like the reference."""
         x /= 0.18215
-        return _run(self._state, arch.VAE_DECODER, x.to(self._device), pad_stride2=False)
+        if self.backend == "torch":
+            return _run(self._state, arch.VAE_DECODER, x.to(self._device), pad_stride2=False)
+        return self.handle().decode(x.to(self._device, torch.float32))
 
     forward = __call__
 

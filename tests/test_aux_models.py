@@ -16,7 +16,7 @@ def test_clip_vae_match_reference():
     c.load_state_dict(sds["clip"], strict=True)
     out = c(torch.from_numpy(g["clip_tokens"]))
     assert (out - torch.from_numpy(g["clip_out"])).abs().max().item() < 2e-5
-    d = VAE_Decoder()
+    d = VAE_Decoder(backend="torch")
     d.load_state_dict(sds["decoder"], strict=True)
     lat = H.seeded((1, 4, 8, 8), 301) * 0.18215 * 3
     lat_in = lat.clone()

@@ -86,3 +86,31 @@ def test_768_generate_runs(models):
     img = pipeline.generate(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, n_inference_steps=2,
                             models=models, seed=1, device=DEV, tokenizer=StubTokenizer(), height=768, width=768)
     assert img.shape == (768, 768, 3)
+
+
+def test_native_vae_decoder_vs_reference():
+    """Native HIP VAE decoder (csrc/vae.hip) vs the reference decoder's golden output (8x8 latents) and vs
+    the torch-op restatement at 64x64 latents (the size generate() uses), incl. quirks Q3/Q4."""
+    from pytorch_stable_diffusion_amd import model_loader
+    from pytorch_stable_diffusion_amd.vae import VAE_Decoder
+    g = H.load_npz("aux.npz")
+    sd = model_loader.synthetic_state_dicts(("decoder",))["decoder"]
+    nat = VAE_Decoder(backend="native")
+    nat.load_state_dict(sd, strict=True)
+    nat.to(DEV)
+    lat = (H.seeded((1, 4, 8, 8), 301) * 0.18215 * 3).to(DEV)
+    img = nat(lat.clone()).cpu()
+    ref = torch.from_numpy(g["dec_out"])
+    rel = H.rel_l2(img, ref)
+    G.log_metric(test="vae_native", size=8, rel_l2=rel, max_abs=(img - ref).abs().max().item())
+    assert rel < 5e-3, f"8x8: rel L2 {rel:.2e}"
+    tor = VAE_Decoder(backend="torch")
+    tor.load_state_dict(sd, strict=True)
+    tor.to(DEV)
+    lat64 = (H.seeded((1, 4, 64, 64), 305) * 0.18215 * 3).to(DEV)
+    a = nat(lat64.clone())
+    b = tor(lat64.clone())
+    rel = H.rel_l2(a.cpu(), b.cpu())
+    mae = ((a - b).abs().mean() / 2).item()
+    G.log_metric(test="vae_native", size=64, rel_l2=rel, pixel_mae=mae, launches=nat.handle().last_launch_count)
+    assert rel < 5e-3 and mae < 1e-3, f"64x64: rel L2 {rel:.2e}, pixel MAE {mae:.2e}"
