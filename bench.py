@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512 pixels)")
     ap.add_argument("--stream-f16", action="store_true", help="fp16 residual stream (default fp32 stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-image-latency", action="store_true", help="skip the end-to-end generate() latency leg")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -173,6 +174,36 @@ def main():
                            "achieved_tflops": round(ALGO_GFLOP_512 * args.steps / (ev_ms * 1e-3) / 1e3, 2) if hw == 64 else None},
         }
 
+    # ---- 50-step image latency: the drop-in generate() end to end (CLIP x2 + 50 fused steps + VAE decode)
+    image_latency = None
+    if rank == 0 and not args.no_image_latency and hw == 64:
+        from pytorch_stable_diffusion_amd import model_loader, pipeline
+        from tests.stub_tokenizer import StubTokenizer
+        aux = model_loader.synthetic_state_dicts(("clip", "decoder"))
+        from pytorch_stable_diffusion_amd.clip import CLIP
+        from pytorch_stable_diffusion_amd.vae import VAE_Decoder
+        clip = CLIP().to(dev)
+        clip.load_state_dict(aux["clip"], strict=True)
+        dec = VAE_Decoder().to(dev)
+        dec.load_state_dict(aux["decoder"], strict=True)
+        models = {"clip": clip, "decoder": dec, "diffusion": model}
+        kw = dict(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, sampler_name="ddpm", models=models,
+                  seed=42, device=dev, tokenizer=StubTokenizer())
+        pipeline.generate(n_inference_steps=3, **kw)           # warm (VAE autotune)
+        torch.cuda.synchronize()
+        t_img = time.perf_counter()
+        pipeline.generate(n_inference_steps=50, **kw)
+        torch.cuda.synchronize()
+        image_latency = (time.perf_counter() - t_img) * 1e3
+        # decoder alone
+        lat_d = torch.randn((1, 4, 64, 64), device=dev)
+        dec(lat_d.clone()); torch.cuda.synchronize()
+        t_d = time.perf_counter()
+        dec(lat_d.clone()); torch.cuda.synchronize()
+        vae_ms = (time.perf_counter() - t_d) * 1e3
+        model.set_context(ctx)          # restore bench context/schedule
+        model.set_schedule(temb)
+
     # ---- CPU baseline: the oracle (fp32 PyTorch-CPU port of the reference path) on this host's cores
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -209,6 +240,10 @@ def main():
                        "launches_per_step": launches, "weights": "synthetic fp16, 859.5M params",
                        "hip_event_ms_per_step": round(ev_ms / args.steps, 3),
                        "latency_50_step_loop_ms": round(elapsed / args.steps * 50e3, 1),
+                       "image_latency_50_steps_ms": None if image_latency is None else round(image_latency, 1),
+                       "vae_decode_ms": None if image_latency is None else round(vae_ms, 2),
+                       "image_latency_note": "pipeline.generate() txt2img 512x512, 50 steps, CFG 7.5: interim torch-ROCm CLIP x2 "
+                                             "+ native fused loop (CPU noise stream uploaded per step) + native HIP VAE decoder",
                        "baseline_note": "vs_baseline divides by the reference's only published number: 6.06 s/it "
                                         "(0.165 steps/s), CPU fp32, sd/inference_demo.ipynb:91",
                        "setup_s": round(t_load, 1)},
