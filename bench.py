@@ -44,30 +44,17 @@ def parse():
 
 
 def synth_weights_flat(manifest, device, rank, world):
-    """fp16 flat weight buffer: generated on rank 0, broadcast over RCCL when world > 1."""
-    from pytorch_stable_diffusion_amd import synth
-    total = sum(int(torch.tensor(s).prod()) for s in manifest.values())
-    flat = torch.empty(total, dtype=torch.float16, device=device)
+    """Flat fp16 weight buffer: generated on rank 0, handed to every rank by ONE RCCL broadcast
+    (pytorch_stable_diffusion_amd.replicas -- the same code the world-2 gloo test exercises)."""
+    from pytorch_stable_diffusion_amd import replicas, synth
+    flat = torch.empty(replicas.flat_size(manifest), dtype=torch.float16, device=device)
     sd_cpu = None
     if rank == 0:
         sd_cpu = synth.synth_state_dict(manifest)
-        off = 0
-        for k, shp in manifest.items():
-            n = sd_cpu[k].numel()
-            flat[off:off + n].copy_(sd_cpu[k].reshape(-1).to(torch.float16))
-            off += n
+        replicas.pack_flat(sd_cpu, manifest, flat)
     if world > 1:
-        import torch.distributed as dist
-        dist.broadcast(flat, src=0)
-    state = {}
-    off = 0
-    for k, shp in manifest.items():
-        n = 1
-        for s in shp:
-            n *= s
-        state[k] = flat[off:off + n].view(*shp)
-        off += n
-    return state, sd_cpu
+        replicas.broadcast_weights(flat, src=0)
+    return replicas.views_from_flat(flat, manifest), sd_cpu
 
 
 def main():
@@ -141,10 +128,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     ev_ms = e0.elapsed_time(e1)
     if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        from pytorch_stable_diffusion_amd import replicas
+        elapsed = replicas.max_over_ranks(elapsed, device=dev)
     launches = h.last_launch_count + 1
 
     # ---- roofline: per-launch HIP events on the forward's own stream, same process, after the timed region
