@@ -23,17 +23,19 @@ namespace {
 template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
-  static constexpr int STG = STG_;   // 0: LDS-DMA ring (global_load_lds); 1: register-staged double buffer
-  static constexpr int NW = WM * WN, NT = 64 * NW;
+  static constexpr int STG = STG_;   // 0: LDS-DMA ring; 1: register-staged double buffer; 2: wave-specialised ring
+  // NW = waves that own MFMA sub-tiles (and, for STG 0/1, also stage).  STG 2 adds NW producer waves that
+  // only issue LDS-DMA, so each SIMD holds one MFMA wave and one DMA wave.
+  static constexpr int NW = WM * WN, NT = 64 * NW * (STG_ == 2 ? 2 : 1);
   static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int RA = BM * 8 / NT, RB = BN * 8 / NT;
+  static constexpr int RA = BM * 8 / (64 * NW), RB = BN * 8 / (64 * NW);
   static constexpr int CS_BYTES = BM * BN * 4;
   static constexpr int LDS = (NS * STAGE > CS_BYTES) ? NS * STAGE : CS_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+  static_assert((BM * 8) % (64 * NW) == 0 && (BN * 8) % (64 * NW) == 0, "staging must divide evenly");
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -51,7 +53,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = C::STG == 2 && wave_id >= NW;       // wave-uniform role (STG 2 only)
+  const int wave = producer ? wave_id - NW : wave_id;        // index inside its role group
   const int wm = wave / C::WN, wn = wave % C::WN;
   // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
   // b+8 share an L2), so a plain map makes every XCD stream the whole activation tensor through its
@@ -193,7 +197,45 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   };
 
   const int nk = kt1 - kt0;
-  if constexpr (C::STG == 1) {
+  if constexpr (C::STG == 2) {
+    // ---- wave-specialised ring: waves [NW, 2NW) issue LDS-DMA NS-1 K-steps ahead, waves [0, NW) run
+    //      ds_read + MFMA.  One s_barrier per K-step for both roles: the producer passes it only after
+    //      the loads of the NEXT step have landed (counted vmcnt), the consumer after it has finished
+    //      reading the current buffer -> the barrier closes both the RAW and the WAR window.
+    constexpr int NS = C::NS;
+    constexpr int G = RA + RB;
+    if (producer) {
+#pragma unroll
+      for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s);
+      {   // step 0 landed?  groups issued after it: min(NS-2, nk-1)
+        const int rem = nk - 1;
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      int nxt = NS - 1;
+      for (int t = 0; t < nk; ++t) {
+        if (t + NS - 1 < nk) stage(nxt);
+        const int rem = nk - 2 - t;           // groups issued after step t+1
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();
+      int cur = 0;
+      for (int t = 0; t < nk; ++t) {
+        compute(cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+      }
+    }
+  } else if constexpr (C::STG == 1) {
     // ---- register-staged double buffer: global_load -> VGPR issued one K-step ahead of its
     //      ds_write_b128, which lands after the MFMAs of the current step (loads fly under the MFMAs).
     f16x8 ra[RA], rb[RB];
@@ -257,6 +299,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 
   // ---- epilogue: accumulators -> LDS (fp32, row-major [BM][BN]) -> coalesced global ----------
   float* Cs = (float*)smem;
+  if (!producer)
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -412,6 +455,8 @@ struct CfgInfo {
   {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
 #define CFG_ENTRY_W(BM, BN, WM, WN, NS, TAG) \
   {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
+#define CFG_ENTRY_P(BM, BN, WM, WN, NS) \
+  {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>}
 #define CFG_ENTRY_R(BM, BN, WM, WN) \
   {"t" #BM "x" #BN "r", BM, BN, 2, Cfg<BM, BN, WM, WN, 2, 1>::NT, Cfg<BM, BN, WM, WN, 2, 1>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, 2, 1>>}
 const CfgInfo kCfgs[] = {
@@ -428,6 +473,10 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY_W(128, 64, 4, 2, 2, "w8"),  CFG_ENTRY_W(64, 128, 2, 4, 2, "w8"),
     CFG_ENTRY_W(256, 128, 4, 4, 2, "w16"), CFG_ENTRY_W(256, 128, 4, 4, 3, "w16"),
     CFG_ENTRY_W(128, 256, 4, 4, 2, "w16"),
+    // wave-specialised (producer/consumer) rings
+    CFG_ENTRY_P(128, 128, 2, 2, 3), CFG_ENTRY_P(128, 128, 2, 2, 4), CFG_ENTRY_P(64, 64, 2, 2, 4),
+    CFG_ENTRY_P(128, 64, 2, 2, 4),  CFG_ENTRY_P(64, 128, 2, 2, 4),
+    CFG_ENTRY_P(256, 128, 4, 2, 3), CFG_ENTRY_P(128, 256, 2, 4, 3),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};
