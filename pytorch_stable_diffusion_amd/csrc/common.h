@@ -76,7 +76,6 @@ struct GemmArgs {
   float* slab;
   int ksplit;
   int ksteps_per;
-  int dbg;             // timing experiments only: 1 skip W loads, 2 skip A loads, 4 skip MFMA (results invalid)
 };
 
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic

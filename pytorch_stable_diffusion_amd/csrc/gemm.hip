@@ -20,10 +20,11 @@
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0, int KPI_ = 1>
 struct Cfg {
+  static constexpr int KPI = KPI_;   // K-steps (of 64) per barrier interval (wave-specialised ring only)
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
-  static constexpr int STG = STG_;   // 0: LDS-DMA ring; 1: register-staged double buffer; 2: wave-specialised ring
+  static constexpr int STG = STG_;   // 0: LDS-DMA ring, every wave stages and computes; 2: producer/consumer wave specialisation
   // NW = waves that own MFMA sub-tiles (and, for STG 0/1, also stage).  STG 2 adds NW producer waves that
   // only issue LDS-DMA, so each SIMD holds one MFMA wave and one DMA wave.
   static constexpr int NW = WM * WN, NT = 64 * NW * (STG_ == 2 ? 2 : 1);
@@ -31,7 +32,8 @@ struct Cfg {
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static constexpr int RA = BM * 8 / (64 * NW), RB = BN * 8 / (64 * NW);
   static constexpr int CS_BYTES = BM * BN * 4;
-  static constexpr int LDS = (NS * STAGE > CS_BYTES) ? NS * STAGE : CS_BYTES;
+  static constexpr int RING = NS * KPI * STAGE;
+  static constexpr int LDS = (RING > CS_BYTES) ? RING : CS_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
@@ -54,8 +56,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = C::STG == 2 && wave_id >= NW;       // wave-uniform role (STG 2 only)
-  const int wave = producer ? wave_id - NW : wave_id;        // index inside its role group
+  // wave-uniform roles (STG 2): waves [0,NW) run ds_read + MFMA, waves [NW,2NW) only issue LDS-DMA
+  const bool producer = C::STG == 2 && wave_id >= NW;
+  const int wave = wave_id % NW;                              // index inside its role group
   const int wm = wave / C::WN, wn = wave % C::WN;
   // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
   // b+8 share an L2), so a plain map makes every XCD stream the whole activation tensor through its
@@ -198,27 +201,38 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 
   const int nk = kt1 - kt0;
   if constexpr (C::STG == 2) {
-    // ---- wave-specialised ring: waves [NW, 2NW) issue LDS-DMA NS-1 K-steps ahead, waves [0, NW) run
-    //      ds_read + MFMA.  One s_barrier per K-step for both roles: the producer passes it only after
-    //      the loads of the NEXT step have landed (counted vmcnt), the consumer after it has finished
-    //      reading the current buffer -> the barrier closes both the RAW and the WAR window.
-    constexpr int NS = C::NS;
-    constexpr int G = RA + RB;
+    // ---- wave-specialised ring: waves [NW, 2NW) issue LDS-DMA NS-1 intervals ahead, waves [0, NW) run
+    //      ds_read + MFMA.  An interval = KPI K-steps; one s_barrier per interval for both roles: the
+    //      producer passes it only after the loads of the NEXT interval have landed (counted vmcnt), the
+    //      consumer after it has finished reading the current buffers -> the barrier closes both the RAW
+    //      and the WAR window.  Ring slot = interval % NS, sub-buffer j of a slot = (slot*KPI + j).
+    constexpr int NS = C::NS, KPI = C::KPI;
+    constexpr int G = (RA + RB) * KPI;      // LDS-DMA instructions per wave per full interval
+    const int ni = (nk + KPI - 1) / KPI;    // intervals (the last may be partial)
     if (producer) {
+      auto stage_interval = [&](int it, int slot) {
+#pragma unroll
+        for (int j = 0; j < KPI; ++j)
+          if (it * KPI + j < nk) stage(slot * KPI + j);
+          else if (KPI > 1) {            // keep the per-interval DMA count constant for counted vmcnt
+#pragma unroll
+            for (int i = 0; i < RA + RB; ++i) glds16(p.zero, smem + ((slot * KPI + j) * C::STAGE) + (i * NW + wave) * 1024);
+          }
+      };
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s);
-      {   // step 0 landed?  groups issued after it: min(NS-2, nk-1)
-        const int rem = nk - 1;
+        if (s < ni) stage_interval(s, s);
+      {
+        const int rem = ni - 1;
         if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
         else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
       int nxt = NS - 1;
-      for (int t = 0; t < nk; ++t) {
-        if (t + NS - 1 < nk) stage(nxt);
-        const int rem = nk - 2 - t;           // groups issued after step t+1
+      for (int t = 0; t < ni; ++t) {
+        if (t + NS - 1 < ni) stage_interval(t + NS - 1, nxt);
+        const int rem = ni - 2 - t;           // intervals issued after interval t+1
         if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
         else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -228,45 +242,13 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     } else {
       __builtin_amdgcn_s_barrier();
       int cur = 0;
-      for (int t = 0; t < nk; ++t) {
-        compute(cur);
+      for (int t = 0; t < ni; ++t) {
+#pragma unroll
+        for (int j = 0; j < KPI; ++j)
+          if (t * KPI + j < nk) compute(cur * KPI + j);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = (cur + 1 == NS) ? 0 : cur + 1;
-      }
-    }
-  } else if constexpr (C::STG == 1) {
-    // ---- register-staged double buffer: global_load -> VGPR issued one K-step ahead of its
-    //      ds_write_b128, which lands after the MFMAs of the current step (loads fly under the MFMAs).
-    f16x8 ra[RA], rb[RB];
-    auto load_regs = [&]() {
-      if (seg_left == 0) open_segment();
-#pragma unroll
-      for (int i = 0; i < RA; ++i) { ra[i] = *(const f16x8*)a_ptr[i]; a_ptr[i] += a_inc[i]; }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) { rb[i] = *(const f16x8*)b_ptr[i]; b_ptr[i] += b_inc[i]; }
-      --seg_left;
-    };
-    auto write_lds = [&](int buf) {
-      char* sa = smem + buf * C::STAGE;
-      char* sb = sa + C::A_BYTES;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) *(f16x8*)(sa + ((i * NW + wave) * 64 + lane) * 16) = ra[i];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) *(f16x8*)(sb + ((i * NW + wave) * 64 + lane) * 16) = rb[i];
-    };
-    if (nk > 0) {
-      load_regs();
-      write_lds(0);
-      if (nk > 1) load_regs();
-      __syncthreads();
-      for (int t = 0; t < nk; ++t) {
-        compute(t & 1);
-        if (t + 1 < nk) {
-          write_lds((t + 1) & 1);
-          if (t + 2 < nk) load_regs();
-        }
-        __syncthreads();
       }
     }
   } else {
@@ -457,8 +439,8 @@ struct CfgInfo {
   {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
 #define CFG_ENTRY_P(BM, BN, WM, WN, NS) \
   {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>}
-#define CFG_ENTRY_R(BM, BN, WM, WN) \
-  {"t" #BM "x" #BN "r", BM, BN, 2, Cfg<BM, BN, WM, WN, 2, 1>::NT, Cfg<BM, BN, WM, WN, 2, 1>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, 2, 1>>}
+#define CFG_ENTRY_P2(BM, BN, WM, WN, NS, KPI) \
+  {"t" #BM "x" #BN "s" #NS "p" #KPI, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, KPI>::NT, Cfg<BM, BN, WM, WN, NS, 2, KPI>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, KPI>>}
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
     CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
@@ -466,8 +448,6 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY(64, 64, 2, 2, 2),   CFG_ENTRY(64, 64, 2, 2, 3),  CFG_ENTRY(64, 64, 2, 2, 4),
     CFG_ENTRY(256, 128, 4, 2, 2), CFG_ENTRY(256, 128, 4, 2, 3),
     CFG_ENTRY(128, 256, 2, 4, 2), CFG_ENTRY(128, 256, 2, 4, 3),
-    CFG_ENTRY_R(128, 128, 2, 2),  CFG_ENTRY_R(128, 64, 2, 2),  CFG_ENTRY_R(64, 128, 2, 2),
-    CFG_ENTRY_R(64, 64, 2, 2),    CFG_ENTRY_R(256, 128, 4, 2), CFG_ENTRY_R(128, 256, 2, 4),
     // 8/16-wave variants: two waves per SIMD so DMA issue / LDS latency of one hides under the other's MFMAs
     CFG_ENTRY_W(128, 128, 2, 4, 2, "w8"), CFG_ENTRY_W(128, 128, 2, 4, 3, "w8"), CFG_ENTRY_W(128, 128, 4, 2, 3, "w8m"),
     CFG_ENTRY_W(128, 64, 4, 2, 2, "w8"),  CFG_ENTRY_W(64, 128, 2, 4, 2, "w8"),
@@ -477,6 +457,9 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY_P(128, 128, 2, 2, 3), CFG_ENTRY_P(128, 128, 2, 2, 4), CFG_ENTRY_P(64, 64, 2, 2, 4),
     CFG_ENTRY_P(128, 64, 2, 2, 4),  CFG_ENTRY_P(64, 128, 2, 2, 4),
     CFG_ENTRY_P(256, 128, 4, 2, 3), CFG_ENTRY_P(128, 256, 2, 4, 3),
+    // two K-steps per barrier interval
+    CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
+    CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};

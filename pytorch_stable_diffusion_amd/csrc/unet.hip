@@ -430,7 +430,6 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.out = d->out; a.out_f32 = d->out_f32; a.ldc = d->ldc; a.out16 = (f16*)d->out16;
   a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
-  { const char* e = getenv("SDMI_GEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
   return sdmi_launch_gemm(a, d->cfg, (hipStream_t)stream);

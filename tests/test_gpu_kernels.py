@@ -25,7 +25,7 @@ def test_library_loaded_is_in_tree():
     assert "pytorch_stable_diffusion_amd/lib/libsdmi.so" in N.lib_path()
 
 
-@pytest.mark.parametrize("cfg", list(range(35)))
+@pytest.mark.parametrize("cfg", list(range(34)))
 def test_gemm_exact_integers(cfg):
     """MFMA fragment layouts: small-integer operands make every product/sum exact, so the result must
     equal the integer matmul bit for bit (asymmetric operands catch transposed/permuted layouts)."""
