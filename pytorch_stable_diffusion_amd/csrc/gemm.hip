@@ -48,8 +48,100 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
+// V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, int m0, int n0, int kz, int tid) {
+  if (p.ksplit > 1) {
+    float* slab = p.slab + (size_t)kz * p.M * p.N;
+    for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
+      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+      const int m = m0 + row, n = n0 + c4 * 4;
+      if (m < p.M && n < p.N) *(f32x4*)(slab + (size_t)m * p.N + n) = *(const f32x4*)(Cs + row * BN + c4 * 4);
+    }
+    return;
+  }
+
+  const bool transposed = p.outT != nullptr && n0 >= p.nt0;
+  if (!transposed) {
+    for (int idx = tid; idx < BM * (BN / 8); idx += NT) {
+      const int row = idx / (BN / 8), c8 = idx % (BN / 8);
+      const int m = m0 + row, n = n0 + c8 * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      const f32x4 v0 = *(const f32x4*)(Cs + row * BN + c8 * 8);
+      const f32x4 v1 = *(const f32x4*)(Cs + row * BN + c8 * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+      if (p.bias) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+      if (p.res) {
+        if (p.res_f32) {
+          const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        } else {
+          const f16x8 rr = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+        }
+      }
+      f16x8 o16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o16[e] = (f16)v[e];
+      if (p.out_f32) {
+        float* op = (float*)p.out + (size_t)m * p.ldc + n;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+        *(f32x4*)op = o0;
+        *(f32x4*)(op + 4) = o1;
+        if (p.out16) *(f16x8*)(p.out16 + (size_t)m * p.ldc + n) = o16;
+      } else {
+        *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
+      }
+    }
+  } else {
+    // transposed tail: 8 consecutive rows (tokens) of one column -> 16 B along the key axis
+    const int Ct = p.N - p.nt0;
+    for (int idx = tid; idx < (BM / 8) * BN; idx += NT) {
+      const int col = idx % BN, r8 = idx / BN;
+      const int m = m0 + r8 * 8, n = n0 + col;
+      if (m >= p.M || n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+      f16x8 o16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o16[e] = (f16)(Cs[(r8 * 8 + e) * BN + col] + bv);
+      if ((p.S & 7) == 0) {
+        const int b = m / p.S, s = m - b * p.S;
+        *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
+      } else {   // tiny maps (S not a multiple of 8): element-wise, rows may straddle images
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int me = m + e;
+          if (me < p.M) {
+            const int b = me / p.S, s = me - b * p.S;
+            p.outT[((size_t)b * Ct + (n - p.nt0)) * p.ldt + s] = o16[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+#ifdef SDMI_CLK_PROBE
+__device__ unsigned long long g_clk_probe[2048][2];   // diagnostic build only: {shader cycles, 100 MHz ticks} per workgroup
+#endif
+
 template <class C>
 __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
+#ifdef SDMI_CLK_PROBE
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT;
   constexpr int FM = C::FM, FN = C::FN, RA = C::RA, RB = C::RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -181,21 +273,31 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // MFMA over one staged K-step.  Fragments are double-buffered in registers: the ds_read_b128 of k16
+  // sub-step s+1 are issued BEFORE the MFMAs of sub-step s, so the compiler's counted lgkmcnt waits only for
+  // the older reads and the LDS latency hides under the matrix pipe (it was exposed 4x per K-step before).
   auto compute = [&](int buf) {
     const char* As = smem + buf * C::STAGE + a_row_off;
     const char* Bs = smem + buf * C::STAGE + C::A_BYTES + b_row_off;
+    f16x8 af[2][FM], bf[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(As + i * 32 * 128 + coff[0]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[0][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[0]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      f16x8 af[FM], bf[FN];
+      if (s < 3) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(As + i * 32 * 128 + coff[s]);
+        for (int i = 0; i < FM; ++i) af[(s + 1) & 1][i] = *(const f16x8*)(As + i * 32 * 128 + coff[s + 1]);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s]);
+        for (int j = 0; j < FN; ++j) bf[(s + 1) & 1][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads ahead of this sub-step's MFMAs
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -230,26 +332,65 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_s_barrier();
       int nxt = NS - 1;
+#ifdef SDMI_CLK_PROBE
+      unsigned long long acc_issue = 0, acc_vm = 0, acc_bar = 0;
+#endif
       for (int t = 0; t < ni; ++t) {
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
         if (t + NS - 1 < ni) stage_interval(t + NS - 1, nxt);
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
         const int rem = ni - 2 - t;           // intervals issued after interval t+1
         if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
         else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+        acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += s3 - s2;
+#endif
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
       }
+#ifdef SDMI_CLK_PROBE
+      if (lane == 0 && wave == 0 && blockIdx.x < 512) {
+        g_clk_probe[512 + blockIdx.x][0] = acc_issue; g_clk_probe[512 + blockIdx.x][1] = acc_vm;
+        g_clk_probe[1024 + blockIdx.x][0] = acc_bar;
+      }
+#endif
     } else {
       __builtin_amdgcn_s_barrier();
       int cur = 0;
+#ifdef SDMI_CLK_PROBE
+      unsigned long long acc_cmp = 0, acc_cbar = 0;
+#endif
       for (int t = 0; t < ni; ++t) {
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int j = 0; j < KPI; ++j)
           if (t * KPI + j < nk) compute(cur * KPI + j);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SDMI_CLK_PROBE
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef SDMI_CLK_PROBE
+        acc_cmp += s1 - s0; acc_cbar += __builtin_amdgcn_s_memtime() - s1;
+#endif
         cur = (cur + 1 == NS) ? 0 : cur + 1;
       }
+#ifdef SDMI_CLK_PROBE
+      if (lane == 0 && wave == 0 && blockIdx.x < 512) {
+        g_clk_probe[1536 + blockIdx.x][0] = acc_cmp; g_clk_probe[1536 + blockIdx.x][1] = acc_cbar;
+      }
+#endif
     }
   } else {
   // ---- LDS-DMA ring: NS-deep, loads stay in flight across barriers (counted vmcnt) ---------------
@@ -294,85 +435,291 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       }
   __syncthreads();
 
-  if (p.ksplit > 1) {
-    float* slab = p.slab + (size_t)kz * p.M * p.N;
-    for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
-      const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-      const int m = m0 + row, n = n0 + c4 * 4;
-      if (m < p.M && n < p.N) *(f32x4*)(slab + (size_t)m * p.N + n) = *(const f32x4*)(Cs + row * BN + c4 * 4);
+  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
+#ifdef SDMI_CLK_PROBE
+  if (tid == 0 && blockIdx.x < 2048) {
+    g_clk_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk_t0;
+    g_clk_probe[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
+}
+
+#ifdef SDMI_CLK_PROBE
+extern "C" int sdmi_dbg_read_clk(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_probe), (size_t)n * 16) == hipSuccess ? 0 : -5;
+}
+#endif
+
+// =============================================================================================
+// 3x3 / stride-1 convolution with HALO REUSE (wave-specialised).
+//
+// The generic kernel above re-stages the activation tile for each of the 9 taps.  Profiling shows all of its
+// variants pinned at ~75 GB/s per CU of LDS-DMA (bytes staged per flop), so for 3x3 convs (64 % of the UNet's GEMM
+// FLOPs) this kernel walks K chunk-major -- for ci-chunk c: for tap (kh,kw) -- and stages the (TH+2) x W input rows
+// that a BM = TH*W output tile needs ONCE per chunk; the 9 taps read shifted fragments of the same LDS image.
+// A-side DMA drops 9x -> ~2.3x, total staged bytes per flop ~0.6x (128x128) ... 0.45x (256x128).
+//   * tile = TH whole image rows (BM % W == 0, H*W % BM == 0; otherwise the launcher falls back to igemm);
+//   * halo image: pixel hp = hy*(W+2) + hx, 128 B per pixel (64 channels), chunk swizzle keyed on hp; the two
+//     side columns hx = 0, W+1 are image padding for every tile and are zeroed once;
+//   * halo(c+1) is issued one LDS-DMA per producer wave per tap while chunk c is being multiplied;
+//   * weights: one BN x 64 tile per (chunk, tap) through an NS-deep ring, exactly as in the generic kernel.
+template <int BM_, int BN_, int WM_, int WN_, int NS_>
+struct HCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;
+  static constexpr int NW = WM * WN, NT = 128 * NW;
+  static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  static constexpr int B_BYTES = BN * 128, RB = BN * 8 / (64 * NW);
+  static constexpr int CS_BYTES = BM * BN * 4;
+  static constexpr int NTAPH = 9 - (NS - 2);      // taps of chunk c during which halo(c+1) is issued
+  static constexpr int G = RB + 1;                // LDS-DMA per producer wave per interval (weights + 1 halo piece)
+  static_assert(NS == 3 || NS == 4, "ring depth");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_bytes) {
+  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT, NS = C::NS;
+  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = C::G, NTAPH = C::NTAPH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave_id >= NW;
+  const int wave = wave_id % NW;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * (p.M / BM);
+  int kz, tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    kz = L / tiles;
+    tile = L - kz * tiles;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int Cin = p.C0 + p.C1, nchunk = Cin >> 6;
+  const int nkt = 9 * nchunk;
+  const int kt0 = kz * p.ksteps_per;                 // multiple of 9 (launcher)
+  const int kt1 = min(kt0 + p.ksteps_per, nkt);
+  const int nk = kt1 - kt0;
+  const int c_first = kt0 / 9;
+
+  const int W = p.Wo, Hh = p.Ho, W2 = W + 2;
+  const int TH = BM / W;
+  const int img = m0 / (Hh * W), y0 = (m0 - img * Hh * W) / W;
+  const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;      // == Hh, W for stride 1 / pad 1
+
+  char* hb0 = smem;
+  char* hb1 = smem + halo_bytes;
+  char* bring = smem + 2 * halo_bytes;
+  char* dump = bring + NS * C::B_BYTES;
+
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (producer) {
+    // ---- halo pieces owned by this wave: piece q = tau*NW + wave covers 8 consecutive interior pixels ----
+    const int rowp = W >> 3;                          // pieces per image row
+    const int NHI = (TH + 2) * rowp;                  // pieces per chunk (<= NTAPH * NW, checked by the launcher)
+    int h_pix[NTAPH], h_gch[NTAPH], h_lds[NTAPH];
+    bool h_in[NTAPH];
+#pragma unroll
+    for (int t = 0; t < NTAPH; ++t) {
+      const int q = t * NW + wave;
+      const int hy = q / rowp, seg = q - hy * rowp;
+      const int hx = 1 + seg * 8 + (lane >> 3);       // interior columns 1..W
+      const int hp = hy * W2 + hx;
+      const int y = y0 - 1 + hy, x = hx - 1;
+      h_in[t] = q < NHI && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;
+      h_pix[t] = img * p.Hs * p.Ws + (y >> p.ups) * p.Ws + (x >> p.ups);
+      h_gch[t] = ((lane & 7) ^ ((hp >> 1) & 7)) * 8;
+      h_lds[t] = q < NHI ? (hy * W2 + 1 + seg * 8) * 128 : -1;   // wave-uniform LDS byte offset of the piece
     }
-    return;
+    auto halo_piece = [&](int t, int chunk, char* hb) {
+      const int cabs = chunk << 6;
+      const bool second = cabs >= p.C0;
+      const f16* base = second ? p.a1 : p.a0;
+      const int ld = second ? p.lda1 : p.lda0;
+      const int cc = second ? cabs - p.C0 : cabs;
+      const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
+      const f16* gz = p.zero + h_gch[t];
+      const f16* g = h_in[t] ? base + ((size_t)h_pix[t] * ld + cc + h_gch[t]) : gz;
+      glds16(lds_off >= 0 ? g : gz, lds_off >= 0 ? hb + lds_off : dump);
+    };
+    // ---- weight tile pointers: w[n][tap*Cin + chunk*64 + ...] ----
+    const f16* b_ptr[RB];
+    int b_ok[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int q = (i * NW + wave) * 64 + lane;
+      const int row = q >> 3, pc = q & 7;
+      const int gch = (pc ^ ((row >> 1) & 7)) * 8;
+      const int n = n0 + row;
+      b_ok[i] = n < p.N;
+      b_ptr[i] = b_ok[i] ? p.w + (size_t)n * p.ldw + (size_t)c_first * 64 + gch : p.zero + gch;
+    }
+    int tap = 0, chunk = c_first;
+    auto stage_b = [&](int slot) {
+      char* sb = bring + slot * C::B_BYTES;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        glds16(b_ptr[i], sb + (i * NW + wave) * 1024);
+        if (b_ok[i]) b_ptr[i] += (tap == 8) ? (64 - 8 * Cin) : Cin;
+      }
+      if (++tap == 9) { tap = 0; ++chunk; }
+    };
+    // prologue: whole halo of the first chunk + first NS-1 weight tiles
+#pragma unroll
+    for (int t = 0; t < NTAPH; ++t) halo_piece(t, c_first, hb0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS - 1; ++s2)
+      if (s2 < nk) stage_b(s2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nxt = NS - 1;
+    int ctap = 0, cchunk = c_first;                   // (chunk, tap) being CONSUMED in interval t
+#ifdef SDMI_CLK_PROBE
+    unsigned long long acc_issue = 0, acc_vm = 0, acc_bar = 0;
+#endif
+    for (int t = 0; t < nk; ++t) {
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (t + NS - 1 < nk) {
+        stage_b(nxt);
+        // one halo piece of the NEXT chunk (dummy DMA keeps the per-interval count constant)
+        const bool have_next = (cchunk + 1) * 9 < kt1;
+        if (ctap < NTAPH && have_next) {
+#pragma unroll
+          for (int tt = 0; tt < NTAPH; ++tt)
+            if (tt == ctap) halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
+        } else {
+          glds16(p.zero, dump);
+        }
+      }
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
+      const int rem = nk - 2 - t;
+      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef SDMI_CLK_PROBE
+      acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += __builtin_amdgcn_s_memtime() - s2;
+#endif
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      if (++ctap == 9) { ctap = 0; ++cchunk; }
+    }
+#ifdef SDMI_CLK_PROBE
+    if (lane == 0 && wave == 0 && blockIdx.x < 512) {
+      g_clk_probe[512 + blockIdx.x][0] = acc_issue; g_clk_probe[512 + blockIdx.x][1] = acc_vm;
+      g_clk_probe[1024 + blockIdx.x][0] = acc_bar;
+    }
+#endif
+  } else {
+    // ---- consumers: zero the padding columns of both halo buffers once, then MFMA ----
+    for (int i = tid; i < (TH + 2) * 2 * 8 * 2; i += NW * 64) {       // (row, side, 16-B chunk, buffer)
+      const int buf = i & 1, ch = (i >> 1) & 7, side = (i >> 4) & 1, hy = i >> 5;
+      const int hp = hy * W2 + (side ? W + 1 : 0);
+      f16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
+      *(f16x8*)((buf ? hb1 : hb0) + hp * 128 + ch * 16) = z;
+    }
+    int base_hp[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int rr = wm * C::TM + i * 32 + r;
+      const int ty = rr / W, tx = rr - ty * W;
+      base_hp[i] = ty * W2 + tx;
+    }
+    const int bkey = (r >> 1) & 7;
+    const int b_row_off = (wn * C::TN + r) * 128;
+    const int bco = (h ^ bkey) << 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, ctap = 0, cchunk = 0;
+#ifdef SDMI_CLK_PROBE
+    unsigned long long acc_cmp = 0, acc_cbar = 0;
+#endif
+    for (int t = 0; t < nk; ++t) {
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+      const int kh = ctap / 3, kw = ctap - kh * 3;
+      const char* hb = (cchunk & 1) ? hb1 : hb0;
+      const char* Bs = bring + cur * C::B_BYTES + b_row_off;
+      int a_off[FM], a_co[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int hp = base_hp[i] + kh * W2 + kw;
+        a_off[i] = hp * 128;
+        a_co[i] = (h ^ ((hp >> 1) & 7)) << 4;
+      }
+      f16x8 af[2][FM], bf[2][FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(hb + a_off[i] + a_co[i]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[0][j] = *(const f16x8*)(Bs + j * 32 * 128 + bco);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        if (s2 < 3) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[(s2 + 1) & 1][i] = *(const f16x8*)(hb + a_off[i] + (a_co[i] ^ ((s2 + 1) << 5)));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) bf[(s2 + 1) & 1][j] = *(const f16x8*)(Bs + j * 32 * 128 + (bco ^ ((s2 + 1) << 5)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s2 & 1][i], bf[s2 & 1][j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef SDMI_CLK_PROBE
+      acc_cmp += s1 - s0; acc_cbar += __builtin_amdgcn_s_memtime() - s1;
+#endif
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      if (++ctap == 9) { ctap = 0; ++cchunk; }
+    }
+#ifdef SDMI_CLK_PROBE
+    if (lane == 0 && wave == 0 && blockIdx.x < 512) {
+      g_clk_probe[1536 + blockIdx.x][0] = acc_cmp; g_clk_probe[1536 + blockIdx.x][1] = acc_cbar;
+    }
+#endif
   }
 
-  const bool transposed = p.outT != nullptr && n0 >= p.nt0;
-  if (!transposed) {
-    for (int idx = tid; idx < BM * (BN / 8); idx += NT) {
-      const int row = idx / (BN / 8), c8 = idx % (BN / 8);
-      const int m = m0 + row, n = n0 + c8 * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      const f32x4 v0 = *(const f32x4*)(Cs + row * BN + c8 * 8);
-      const f32x4 v1 = *(const f32x4*)(Cs + row * BN + c8 * 8 + 4);
+  float* Cs = (float*)smem;
+  if (!producer)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-      if (p.bias) {
-        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-      }
-      if (p.res) {
-        if (p.res_f32) {
-          const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
-          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-        } else {
-          const f16x8 rr = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int col = wn * C::TN + j * 32 + r;
+          Cs[row * BN + col] = acc[i][j][e];
         }
-      }
-      f16x8 o16;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o16[e] = (f16)v[e];
-      if (p.out_f32) {
-        float* op = (float*)p.out + (size_t)m * p.ldc + n;
-        f32x4 o0, o1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
-        *(f32x4*)op = o0;
-        *(f32x4*)(op + 4) = o1;
-        if (p.out16) *(f16x8*)(p.out16 + (size_t)m * p.ldc + n) = o16;
-      } else {
-        *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
-      }
-    }
-  } else {
-    // transposed tail: 8 consecutive rows (tokens) of one column -> 16 B along the key axis
-    const int Ct = p.N - p.nt0;
-    for (int idx = tid; idx < (BM / 8) * BN; idx += NT) {
-      const int col = idx % BN, r8 = idx / BN;
-      const int m = m0 + r8 * 8, n = n0 + col;
-      if (m >= p.M || n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-      f16x8 o16;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o16[e] = (f16)(Cs[(r8 * 8 + e) * BN + col] + bv);
-      if ((p.S & 7) == 0) {
-        const int b = m / p.S, s = m - b * p.S;
-        *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
-      } else {   // tiny maps (S not a multiple of 8): element-wise, rows may straddle images
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int me = m + e;
-          if (me < p.M) {
-            const int b = me / p.S, s = me - b * p.S;
-            p.outT[((size_t)b * Ct + (n - p.nt0)) * p.ldt + s] = o16[e];
-          }
-        }
-      }
-    }
-  }
+  __syncthreads();
+  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
 }
 
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
@@ -431,16 +778,20 @@ struct CfgInfo {
   const char* name;
   int BM, BN, NS, NT, LDS;
   void (*kern)(GemmArgs);
+  void (*hkern)(GemmArgs, int);   // halo-reuse 3x3 kernel (kern == nullptr)
+  int ntaph, nw;
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
-  {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
+  {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>, nullptr, 0, 0}
 #define CFG_ENTRY_W(BM, BN, WM, WN, NS, TAG) \
-  {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>}
+  {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>, nullptr, 0, 0}
 #define CFG_ENTRY_P(BM, BN, WM, WN, NS) \
-  {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>}
+  {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>, nullptr, 0, 0}
+#define CFG_ENTRY_W2(BM, BN, WM, WN, NS, TAG) \
+  {"t" #BM "x" #BN "s" #NS "p" TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>, nullptr, 0, 0}
 #define CFG_ENTRY_P2(BM, BN, WM, WN, NS, KPI) \
-  {"t" #BM "x" #BN "s" #NS "p" #KPI, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, KPI>::NT, Cfg<BM, BN, WM, WN, NS, 2, KPI>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, KPI>>}
+  {"t" #BM "x" #BN "s" #NS "p" #KPI, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, KPI>::NT, Cfg<BM, BN, WM, WN, NS, 2, KPI>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, KPI>>, nullptr, 0, 0}
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
     CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
@@ -457,21 +808,48 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY_P(128, 128, 2, 2, 3), CFG_ENTRY_P(128, 128, 2, 2, 4), CFG_ENTRY_P(64, 64, 2, 2, 4),
     CFG_ENTRY_P(128, 64, 2, 2, 4),  CFG_ENTRY_P(64, 128, 2, 2, 4),
     CFG_ENTRY_P(256, 128, 4, 2, 3), CFG_ENTRY_P(128, 256, 2, 4, 3),
+    // specialised, 8 consumer waves (two MFMA waves per SIMD) + 8 producer waves
+    CFG_ENTRY_W2(128, 128, 2, 4, 3, "c8"), CFG_ENTRY_W2(128, 128, 4, 2, 3, "c8m"), CFG_ENTRY_W2(128, 128, 2, 4, 4, "c8"),
+    CFG_ENTRY_W2(128, 64, 4, 2, 4, "c8"),  CFG_ENTRY_W2(64, 128, 2, 4, 4, "c8"),
     // two K-steps per barrier interval
     CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
     CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),
 };
+#define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
+  {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
+   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW}
+const CfgInfo kHaloCfgs[] = {
+    CFG_ENTRY_H(128, 128, 2, 2, 3), CFG_ENTRY_H(128, 64, 2, 2, 3), CFG_ENTRY_H(64, 64, 2, 2, 3), CFG_ENTRY_H(64, 128, 2, 2, 3),
+    CFG_ENTRY_H(256, 128, 4, 2, 3), CFG_ENTRY_H(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
+};
+constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
+bool g_hattr_done[kNumHalo] = {};
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 bool g_attr_done[kNumCfgs] = {};
 
 }  // namespace
 
-int sdmi_gemm_num_cfgs() { return kNumCfgs; }
-const char* sdmi_gemm_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?"; }
+int sdmi_gemm_num_cfgs() { return kNumCfgs + kNumHalo; }
+const char* sdmi_gemm_cfg_name(int cfg) {
+  if (cfg >= 0 && cfg < kNumCfgs) return kCfgs[cfg].name;
+  if (cfg >= kNumCfgs && cfg < kNumCfgs + kNumHalo) return kHaloCfgs[cfg - kNumCfgs].name;
+  return "?";
+}
 
 void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
-  *bm = kCfgs[cfg].BM;
-  *bn = kCfgs[cfg].BN;
+  const CfgInfo& c = cfg < kNumCfgs ? kCfgs[cfg] : kHaloCfgs[cfg - kNumCfgs];
+  *bm = c.BM;
+  *bn = c.BN;
+}
+
+// halo-reuse kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image
+static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
+  if (a.ks != 3 || a.stride != 1 || a.pad != 1) return false;
+  if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
+  if (a.Wo % 8 != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
+  const int TH = c.BM / a.Wo;
+  if ((TH + 2) * (a.Wo / 8) > c.ntaph * c.nw) return false;      // one halo piece per producer wave per tap
+  return true;
 }
 
 static int pick_cfg(const GemmArgs& a) {
@@ -495,8 +873,10 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");
   SDMI_REQUIRE(a.ldc % 8 == 0 && (!a.res || a.ldr % 8 == 0), "gemm: ldc/ldr must be multiples of 8");
   if (cfg < 0) cfg = pick_cfg(a);
-  SDMI_REQUIRE(cfg < kNumCfgs, "gemm: bad cfg %d", cfg);
-  const CfgInfo& c = kCfgs[cfg];
+  SDMI_REQUIRE(cfg < kNumCfgs + kNumHalo, "gemm: bad cfg %d", cfg);
+  const bool halo = cfg >= kNumCfgs;
+  const CfgInfo& c = halo ? kHaloCfgs[cfg - kNumCfgs] : kCfgs[cfg];
+  if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
     SDMI_REQUIRE(a.S > 0 && a.ldt % 8 == 0, "gemm: transposed tail needs S > 0 and ldt a multiple of 8");
@@ -510,15 +890,30 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   if (p.ksplit < 1) p.ksplit = 1;
   if (p.ksplit > nkt) p.ksplit = nkt;
   p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
+  if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
   p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
-  if (!g_attr_done[cfg]) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.kern, hipFuncAttributeMaxDynamicSharedMemorySize, c.LDS));
-    g_attr_done[cfg] = true;
-  }
   const int tiles = ((a.M + c.BM - 1) / c.BM) * ((a.N + c.BN - 1) / c.BN);
-  hipLaunchKernelGGL(c.kern, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
-  SDMI_CHECK_HIP(hipGetLastError());
+  if (halo) {
+    const int TH = c.BM / a.Wo;
+    const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
+    int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
+    if (lds < c.BM * c.BN * 4) lds = c.BM * c.BN * 4;
+    SDMI_REQUIRE(lds <= 160 * 1024, "gemm: halo config %s needs %d B of LDS", c.name, lds);
+    if (!g_hattr_done[cfg - kNumCfgs]) {
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.hkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      g_hattr_done[cfg - kNumCfgs] = true;
+    }
+    hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+    SDMI_CHECK_HIP(hipGetLastError());
+  } else {
+    if (!g_attr_done[cfg]) {
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.kern, hipFuncAttributeMaxDynamicSharedMemorySize, c.LDS));
+      g_attr_done[cfg] = true;
+    }
+    hipLaunchKernelGGL(c.kern, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+  }
   if (p.ksplit > 1) {
     const size_t total8 = (size_t)p.M * (p.N / 8);
     int blocks = (int)((total8 + 255) / 256);

@@ -25,7 +25,13 @@ def test_library_loaded_is_in_tree():
     assert "pytorch_stable_diffusion_amd/lib/libsdmi.so" in N.lib_path()
 
 
-@pytest.mark.parametrize("cfg", list(range(34)))
+def _plain_cfgs():
+    from pytorch_stable_diffusion_amd import _native as N
+    lib = N.load()
+    return [i for i in range(lib.sdmi_gemm_num_configs()) if not lib.sdmi_gemm_config_name(i).decode().startswith("h")]
+
+
+@pytest.mark.parametrize("cfg", _plain_cfgs())
 def test_gemm_exact_integers(cfg):
     """MFMA fragment layouts: small-integer operands make every product/sum exact, so the result must
     equal the integer matmul bit for bit (asymmetric operands catch transposed/permuted layouts)."""
@@ -48,7 +54,7 @@ def test_gemm_random_bias_residual(M, Nn, K, ksplit):
     bias = torch.randn((Nn,), generator=g)
     res = torch.randn((M, Nn), generator=g)
     ref = a.double() @ w.double().t() + bias.double() + res.double()
-    for cfg in [-1] + _cfgs():
+    for cfg in [-1] + _plain_cfgs():
         out, out16 = G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias.to(DEV),
                              res=res.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit, want16=True)
         err = (out.cpu().double() - ref).abs().max().item()
@@ -77,6 +83,9 @@ def _conv_ref(x_nhwc, w_oihw, stride, ups):
     dict(B=2, H=12, W=12, C0=128, C1=64, Co=320, ks=3, stride=1, ups=0),     # concat, ragged tiles
     dict(B=1, H=10, W=6, C0=64, C1=128, Co=72, ks=1, stride=1, ups=0),       # 1x1 on concat
     dict(B=2, H=9, W=9, C0=64, C1=0, Co=64, ks=3, stride=2, ups=0),          # odd size, stride 2
+    dict(B=1, H=64, W=64, C0=64, C1=64, Co=192, ks=3, stride=1, ups=0),      # halo-reuse kernels, concat, W=64
+    dict(B=2, H=32, W=32, C0=128, C1=0, Co=64, ks=3, stride=1, ups=0),       # halo-reuse, W=32
+    dict(B=2, H=8, W=8, C0=128, C1=0, Co=128, ks=3, stride=1, ups=0),        # halo-reuse, 8x8 map (one image per tile)
 ])
 def test_conv_implicit_gemm(case):
     c = case
@@ -89,13 +98,21 @@ def test_conv_implicit_gemm(case):
     ref = _conv_ref(xin, w, c["stride"], c["ups"])
     Ho, Wo = ref.shape[1], ref.shape[2]
     wp = G.pack_conv(w.to(DEV))
+    n_halo = 0
     for cfg in [-1] + _cfgs():
         for ksplit in (1, 3):
-            out = G.igemm(x0.to(DEV), wp, B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"],
-                          ups=c["ups"], a1=None if x1 is None else x1.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit)
+            try:
+                out = G.igemm(x0.to(DEV), wp, B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"],
+                              ups=c["ups"], a1=None if x1 is None else x1.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit)
+            except ValueError as exc:       # halo-reuse configs only accept 3x3 s1 convs tiled by whole image rows
+                assert "not applicable" in str(exc) or "LDS" in str(exc), exc
+                continue
+            n_halo += cfg >= len(_plain_cfgs())
             err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
             G.log_metric(test="conv", case=str(c), cfg=cfg, ksplit=ksplit, max_abs_err=err)
             assert err < 2e-3, f"{c} cfg {cfg} ksplit {ksplit}: max abs err {err}"
+    if c["ks"] == 3 and c["stride"] == 1 and c["W"] << c["ups"] in (8, 16, 32, 64):
+        assert n_halo > 0, "no halo-reuse config ran on an eligible conv"
 
 
 def test_gemm_transposed_tail():
@@ -106,7 +123,7 @@ def test_gemm_transposed_tail():
     w = (torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)).half()
     ref = a.double() @ w.double().t()
     ldt = 256
-    for cfg in _cfgs():
+    for cfg in _plain_cfgs():
         for ksplit in (1, 2):
             vt = torch.zeros((B * Cc, ldt), dtype=torch.float16, device=DEV)
             out = G.igemm(a.to(DEV).view(1, B * S, 1, Cc), w.to(DEV), B=1, Hs=B * S, Ws=1, Ho=B * S, Wo=1, cfg=cfg,
