@@ -82,6 +82,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: 
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
 void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn);
+bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg);
 size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int cfg, int ksplit);
 
 // ---------------------------------------------------------------------------------------------

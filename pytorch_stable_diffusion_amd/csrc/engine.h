@@ -277,7 +277,7 @@ struct Engine {
     for (int cfg = 0; cfg < sdmi_gemm_num_cfgs(); ++cfg) {
       int bm, bn;
       sdmi_gemm_cfg_dims(cfg, &bm, &bn);
-      if (a0.outT && (a0.nt0 % bn) != 0) continue;
+      if (!sdmi_gemm_cfg_applicable(a0, cfg)) continue;
       const int tiles = ((a0.M + bm - 1) / bm) * ((a0.N + bn - 1) / bn);
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;

@@ -852,6 +852,19 @@ static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
   return true;
 }
 
+bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
+  if (cfg < 0 || cfg >= kNumCfgs + kNumHalo) return false;
+  const CfgInfo& c = cfg < kNumCfgs ? kCfgs[cfg] : kHaloCfgs[cfg - kNumCfgs];
+  if (a.outT && (a.nt0 % c.BN) != 0) return false;
+  if (cfg >= kNumCfgs) {
+    if (!halo_ok(a, c)) return false;
+    const int TH = c.BM / a.Wo;
+    const int hb = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
+    if (2 * hb + c.NS * c.BN * 128 + 1024 > 160 * 1024) return false;
+  }
+  return true;
+}
+
 static int pick_cfg(const GemmArgs& a) {
   // heuristic default (the UNet plan autotunes over all cfgs x split-K instead)
   if (a.M <= 64) return 9;                                         // t64x64s4
