@@ -24,7 +24,7 @@ template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0, int KPI_ = 
 struct Cfg {
   static constexpr int KPI = KPI_;   // K-steps (of 64) per barrier interval (wave-specialised ring only)
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
-  static constexpr int STG = STG_;   // 0: LDS-DMA ring, every wave stages and computes; 2: producer/consumer wave specialisation
+  static constexpr int STG = STG_;   // 0: every wave stages and computes; 2: producer/consumer wave specialisation
   // NW = waves that own MFMA sub-tiles (and, for STG 0/1, also stage).  STG 2 adds NW producer waves that
   // only issue LDS-DMA, so each SIMD holds one MFMA wave and one DMA wave.
   static constexpr int NW = WM * WN, NT = 64 * NW * (STG_ == 2 ? 2 : 1);
