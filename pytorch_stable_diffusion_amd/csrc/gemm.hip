@@ -64,31 +64,49 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 
   const bool transposed = p.outT != nullptr && n0 >= p.nt0;
   if (!transposed) {
-    for (int idx = tid; idx < BM * (BN / 8); idx += NT) {
+    // Phase 1 issues EVERY residual / bias load of this thread's items before anything consumes them, so the tile
+    // pays one memory latency instead of one per item (a one-K-step workgroup used to live 14 K cycles, most of
+    // it in this loop).  Phase 2 reads the tile from LDS, adds, converts and stores.
+    constexpr int ITEMS = (BM * (BN / 8) + NT - 1) / NT;
+    f32x4 r0[ITEMS], r1[ITEMS], b0[ITEMS], b1[ITEMS];
+    f16x8 rh[ITEMS];
+    bool ok[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = it * NT + tid;
       const int row = idx / (BN / 8), c8 = idx % (BN / 8);
       const int m = m0 + row, n = n0 + c8 * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
+      ok[it] = idx < BM * (BN / 8) && m < p.M && n < p.N;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r0[it][e] = 0.f; r1[it][e] = 0.f; b0[it][e] = 0.f; b1[it][e] = 0.f; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rh[it][e] = (f16)0.f;
+      if (ok[it]) {
+        if (p.bias) { b0[it] = *(const f32x4*)(p.bias + n); b1[it] = *(const f32x4*)(p.bias + n + 4); }
+        if (p.res) {
+          if (p.res_f32) {
+            const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+            r0[it] = *(const f32x4*)rp;
+            r1[it] = *(const f32x4*)(rp + 4);
+          } else {
+            rh[it] = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      if (!ok[it]) continue;
+      const int idx = it * NT + tid;
+      const int row = idx / (BN / 8), c8 = idx % (BN / 8);
+      const int m = m0 + row, n = n0 + c8 * 8;
       const f32x4 v0 = *(const f32x4*)(Cs + row * BN + c8 * 8);
       const f32x4 v1 = *(const f32x4*)(Cs + row * BN + c8 * 8 + 4);
+      float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-      if (p.bias) {
-        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-      }
-      if (p.res) {
-        if (p.res_f32) {
-          const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
-          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-        } else {
-          const f16x8 rr = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v0[e] + b0[it][e] + r0[it][e] + (float)rh[it][e];
+        v[4 + e] = v1[e] + b1[it][e] + r1[it][e] + (float)rh[it][4 + e];
       }
       f16x8 o16;
 #pragma unroll

@@ -6,10 +6,12 @@ import numpy as np, torch
 from tools.gemm_sweep import bench, names
 from pytorch_stable_diffusion_amd import _native as N
 lib = C.CDLL(os.environ["SDMI_LIB"])
+KK = int(os.environ.get("PROBE_K", "5760"))
+KS = int(os.environ.get("PROBE_KS", "3"))
 for cfgname in sys.argv[1:]:
     cfg = names.index(cfgname)
     for _ in range(3):
-        bench(8192, 320, 5760, ks=3, H=64, cfgs=[cfg], splits=(1,), iters=200)
+        bench(8192, 320, KK, ks=KS, H=64, cfgs=[cfg], splits=(1,), iters=200)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (2 * 2048))()
     lib.sdmi_dbg_read_clk(buf, 2048)
