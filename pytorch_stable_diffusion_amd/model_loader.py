@@ -1,8 +1,8 @@
 """Build the ``models`` dict that ``pipeline.generate`` consumes (reference: sd/model_loader.py:9-50).
 
-``preload_models_from_state_dicts`` takes the four state dicts the reference's converter produces
-(sd/model_converter.py:3-1056 -> {'clip','encoder','decoder','diffusion'}); the checkpoint converter itself is
-out of scope.  ``preload_models_synthetic`` builds the name-keyed synthetic set used by
+``preload_models_from_standard_weights`` mirrors the reference's loader (checkpoint -> converter -> models);
+``preload_models_from_state_dicts`` takes the four converted state dicts
+({'clip','encoder','decoder','diffusion'}, sd/model_converter.py:3-1056).  ``preload_models_synthetic`` builds the name-keyed synthetic set used by
 tests and benchmarks (no checkpoint offline)."""
 from __future__ import annotations
 
@@ -27,6 +27,14 @@ def preload_models_from_state_dicts(state_dicts: Dict[str, Dict[str, torch.Tenso
     clip = CLIP().to(device)
     clip.load_state_dict(state_dicts["clip"], strict=True)
     return {"clip": clip, "encoder": encoder, "decoder": decoder, "diffusion": diffusion}
+
+
+def preload_models_from_standard_weights(ckpt_path: str, device) -> Dict[str, object]:
+    """Same entry point as the reference (sd/model_loader.py:9-50): load a standard SD-v1.x checkpoint, convert
+    its keys (``model_converter``), build the four models on ``device``."""
+    from . import model_converter
+    state_dicts = model_converter.load_from_standard_weights(ckpt_path, "cpu")
+    return preload_models_from_state_dicts(state_dicts, device)
 
 
 def synthetic_state_dicts(which=("clip", "encoder", "decoder", "diffusion")) -> Dict[str, Dict[str, torch.Tensor]]:
