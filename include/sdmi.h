@@ -112,6 +112,15 @@ void sdmi_vae_destroy(sdmi_vae* v);
 int sdmi_vae_decode(sdmi_vae* v, const float* latents_dev, float* image_dev, int batch, int h, int w, void* stream);
 int sdmi_vae_last_launch_count(const sdmi_vae* v);
 
+/* ---- CLIP text encoder (reference sd/clip.py:227-261) ------------------------------------------------
+ * tensors: the 148-entry state dict of CLIP (sd/model_converter.py:885-1008,1031-1054).
+ * tokens_dev: (batch, 77) int64 token ids; out_dev: (batch, 77, 768) fp32. */
+typedef struct sdmi_clip sdmi_clip;
+int sdmi_clip_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_clip** out);
+void sdmi_clip_destroy(sdmi_clip* c);
+int sdmi_clip_encode(sdmi_clip* c, const int64_t* tokens_dev, float* out_dev, int batch, void* stream);
+int sdmi_clip_last_launch_count(const sdmi_clip* c);
+
 /* ---- kernel-level entry points (parity tests / micro-benchmarks) ------------------------------ */
 
 /* Implicit-GEMM conv / linear:  out[m][n] = sum_k A(m,k) w[n][k] + bias[n] + res[m][n].

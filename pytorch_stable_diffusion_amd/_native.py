@@ -58,6 +58,10 @@ _SIGNATURES = {
     "sdmi_vae_destroy": (None, [C.c_void_p]),
     "sdmi_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_vae_last_launch_count": (C.c_int, [C.c_void_p]),
+    "sdmi_clip_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdmi_clip_destroy": (None, [C.c_void_p]),
+    "sdmi_clip_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "sdmi_clip_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sdmi_bench_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sdmi_gemm_num_configs": (C.c_int, []),
@@ -187,6 +191,41 @@ class VaeDecoderHandle:
     @property
     def last_launch_count(self) -> int:
         return self._lib.sdmi_vae_last_launch_count(self._h)
+
+
+class ClipHandle:
+    """Owns one native sdmi_clip (CLIP text encoder)."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], flags: int = 0):
+        lib = load()
+        descs, keep = _tensor_descs(state)
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(lib.sdmi_clip_create(descs, len(state), flags, C.byref(h)), "sdmi_clip_create")
+        del keep
+        self._h, self._lib = h, lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdmi_clip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, tokens: torch.Tensor) -> torch.Tensor:
+        assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.shape[1] == 77
+        tokens = tokens.contiguous()
+        out = torch.empty((tokens.shape[0], 77, 768), dtype=torch.float32, device=tokens.device)
+        check(self._lib.sdmi_clip_encode(self._h, ptr(tokens), ptr(out), tokens.shape[0], cur_stream()), "sdmi_clip_encode")
+        return out
+
+    @property
+    def last_launch_count(self) -> int:
+        return self._lib.sdmi_clip_last_launch_count(self._h)
 
 
 class UNetHandle:

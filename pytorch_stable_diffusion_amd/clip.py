@@ -1,6 +1,7 @@
-"""CLIP text encoder with the reference's interface and weight ABI (sd/clip.py:7-261) -- INTERIM
-PyTorch-ROCm implementation (13 GFLOP twice per image, <1 % of one UNet step).
-12 pre-norm layers, 12 heads, causal mask, quick-GELU ``x * sigmoid(1.702 x)``, final LayerNorm."""
+"""CLIP text encoder with the reference's interface and weight ABI (sd/clip.py:7-261): 12 pre-norm layers,
+12 heads, causal mask, quick-GELU ``x * sigmoid(1.702 x)``, final LayerNorm.
+Default backend: native HIP (csrc/clip.hip).  The torch-op restatement below is the explicit ``backend="torch"``
+path used by CPU unit tests."""
 from __future__ import annotations
 
 import math
@@ -13,11 +14,47 @@ from .vae import _StateModule
 
 
 class CLIP(_StateModule):
-    def __init__(self):
+    """``backend="native"`` (default): hand-written HIP kernels through libsdmi (csrc/clip.hip), cuda device
+    required, no fallback.  ``backend="torch"``: explicit opt-in to the PyTorch-op restatement (CPU unit tests)."""
+
+    def __init__(self, backend: str = "native"):
         super().__init__(arch.clip_manifest())
+        if backend not in ("native", "torch"):
+            raise ValueError(f"unknown backend {backend}")
+        self.backend = backend
+        self._handle = None
+
+    def load_state_dict(self, state, strict: bool = True):
+        super().load_state_dict(state, strict)
+        self._drop()
+        return self
+
+    def to(self, device):
+        before = self._device
+        super().to(device)
+        if self._device != before:
+            self._drop()
+        return self
+
+    def _drop(self):
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = None
+
+    def handle(self):
+        from . import _native
+        if self._handle is None:
+            if self._device.type != "cuda":
+                raise RuntimeError("CLIP(backend='native') needs a cuda (ROCm) device; there is no CPU fallback "
+                                   "(use backend='torch' explicitly for a PyTorch-op restatement)")
+            with torch.cuda.device(self._device):
+                self._handle = _native.ClipHandle(self._state)
+        return self._handle
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
+        if self.backend == "native":
+            return self.handle().encode(tokens.to(self._device).type(torch.long))
         sd = self._state
         tokens = tokens.to(self._device).type(torch.long)
         x = F.embedding(tokens, sd["embedding.token_embedding.weight"]) + sd["embedding.position_embedding"]

@@ -149,14 +149,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
     }
-    if constexpr (MASKED) {   // keys beyond Skv (last, ragged tile only)
+    if constexpr (MASKED) {   // keys beyond Skv (ragged last tile) and, for causal attention, keys after the query
       const int kbase_i = t * 64 + 4 * h;
+      const int qlim = p.causal ? q0 + r : 0x7fffffff;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kbase_i + kb * 32 + (e & 3) + 8 * (e >> 2);
-          if (key >= p.Skv) sacc[kb][e] = -INFINITY;
+          if (key >= p.Skv || key > qlim) sacc[kb][e] = -INFINITY;
         }
     }
     // online softmax (per query = per lane; the two half-waves hold disjoint keys).  Lazy rescale:
@@ -220,16 +221,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const bool ragged = (p.Skv & 63) != 0;
-  const int nfull = ragged ? ntiles - 1 : ntiles;
+  const int nfull = p.causal ? 0 : (ragged ? ntiles - 1 : ntiles);   // tiles that need no masking
   int cur = 0;
-  for (int t = 0; t < nfull; ++t) {
+  for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) stage(cur ^ 1);
-    tile_body(std::false_type{}, t, cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (t < nfull) tile_body(std::false_type{}, t, cur);
+    else tile_body(std::true_type{}, t, cur);
+    if (t + 1 < ntiles) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     cur ^= 1;
   }
-  if (ragged) tile_body(std::true_type{}, ntiles - 1, cur);
 
   // ---- normalise and store: lane = query row, registers = head-dim ----
   const float l_tot = l_run + __shfl_xor(l_run, 32);

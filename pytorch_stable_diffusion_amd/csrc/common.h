@@ -76,6 +76,7 @@ struct GemmArgs {
   float* slab;
   int ksplit;
   int ksteps_per;
+  int act;             // epilogue activation after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170)
 };
 
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
@@ -96,6 +97,7 @@ struct AttnArgs {
   int k_batch_stride;        // rows of k per batch (>= Skv)
   const f16* zero;
   float scale;               // 1/sqrt(d)
+  int causal;                // 1: key index > query index is masked (CLIP, sd/attention.py:58-62)
 };
 int sdmi_launch_attention(const AttnArgs& a, hipStream_t st);
 
@@ -122,6 +124,7 @@ struct LnArgs {
   const float* gamma; const float* beta;
   float eps;
   f16* y;
+  float* y32;                 // optional fp32 copy of the output (CLIP's final LayerNorm)
 };
 int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st);
 
@@ -142,6 +145,8 @@ int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float*
 int sdmi_launch_row_softmax(const f16* s, f16* p, int rows, int L, float scale, hipStream_t st);
 int sdmi_launch_q4_reinterpret_add(const float* o, const void* x, int x_f32, void* y, int y_f32, f16* y16, int B, int P,
                                    int C, hipStream_t st);
+int sdmi_launch_clip_embed(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* out, f16* out16,
+                           int rows, int T, int C, int vocab, hipStream_t st);
 int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* b, float* y, int B, int Cin, int Cout,
                                    size_t HW, float in_scale, hipStream_t st);
 int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,

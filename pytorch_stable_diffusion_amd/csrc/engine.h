@@ -252,7 +252,7 @@ struct Engine {
   int gemm(GemmArgs a) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks, a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0), a.Wo, a.outT ? a.nt0 + 1 : 0);
+    ShapeKey key(a.M, a.N, a.K, a.ks, a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan pl;

@@ -105,8 +105,17 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = v0[e] + b0[it][e] + r0[it][e] + (float)rh[it][e];
-        v[4 + e] = v1[e] + b1[it][e] + r1[it][e] + (float)rh[it][4 + e];
+        v[e] = v0[e] + b0[it][e];
+        v[4 + e] = v1[e] + b1[it][e];
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += r0[it][e] + (float)rh[it][e];
+        v[4 + e] += r1[it][e] + (float)rh[it][4 + e];
       }
       f16x8 o16;
 #pragma unroll
@@ -758,6 +767,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     if (p.bias) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    }
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
     }
     const bool transposed = p.outT != nullptr && n >= p.nt0;
     if (transposed) {

@@ -292,6 +292,20 @@ __global__ __launch_bounds__(256) void conv1x1_nchw_small_kernel(const float* x,
   }
 }
 
+// CLIP embedding (sd/clip.py:34-63): out[row] = token_embedding[tokens[row]] + position_embedding[row % T]
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int64_t* tokens, const float* tok_emb, const float* pos_emb,
+                                                         float* out, f16* out16, int rows, int T, int C, int vocab) {
+  const size_t total = (size_t)rows * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / C), c = (int)(i - (size_t)row * C);
+    long long tk = tokens[row];
+    tk = tk < 0 ? 0 : (tk >= vocab ? vocab - 1 : tk);
+    const float v = tok_emb[(size_t)tk * C + c] + pos_emb[(size_t)(row % T) * C + c];
+    out[i] = v;
+    out16[i] = (f16)v;
+  }
+}
+
 inline int nblocks(size_t n, int per = 256, int cap = 4096) {
   size_t b = (n + per - 1) / per;
   if (b > (size_t)cap) b = cap;
@@ -398,6 +412,14 @@ int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* 
   SDMI_REQUIRE(Cin <= 8 && Cout <= 8, "conv1x1_nchw_small: Cin=%d Cout=%d", Cin, Cout);
   hipLaunchKernelGGL(conv1x1_nchw_small_kernel, dim3(nblocks((size_t)B * HW)), dim3(256), 0, st, x, w, b, y, B, Cin, Cout,
                      HW, in_scale);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_clip_embed(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* out, f16* out16,
+                           int rows, int T, int C, int vocab, hipStream_t st) {
+  hipLaunchKernelGGL(clip_embed_kernel, dim3(nblocks((size_t)rows * C)), dim3(256), 0, st, tokens, tok_emb, pos_emb, out,
+                     out16, rows, T, C, vocab);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

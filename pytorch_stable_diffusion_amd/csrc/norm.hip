@@ -183,8 +183,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
       const int c = c8 * 8;
       f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * p.gamma[c + e] + p.beta[c + e]);
-      *(f16x8*)(p.y + (size_t)row * p.C + c) = o;
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (v[i][e] - mean) * rstd * p.gamma[c + e] + p.beta[c + e];
+        o[e] = (f16)yv;
+        if (p.y32) p.y32[(size_t)row * p.C + c + e] = yv;
+      }
+      if (p.y) *(f16x8*)(p.y + (size_t)row * p.C + c) = o;
     }
   }
 }
@@ -221,7 +225,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
 
 int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st) {
   SDMI_REQUIRE(a.C % 8 == 0 && a.C <= 8 * 64 * 3, "layernorm: C=%d unsupported", a.C);
-  SDMI_REQUIRE(a.x && a.y && a.gamma && a.beta && a.M > 0, "layernorm: bad args");
+  SDMI_REQUIRE(a.x && (a.y || a.y32) && a.gamma && a.beta && a.M > 0, "layernorm: bad args");
   const int nch = (a.C / 8 + 63) / 64;
   dim3 grid((a.M + 3) / 4), block(256);
   if (nch == 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, a);

@@ -12,7 +12,7 @@ from tests import helpers as H
 def test_clip_vae_match_reference():
     g = H.load_npz("aux.npz")
     sds = model_loader.synthetic_state_dicts(("clip", "encoder", "decoder"))
-    c = CLIP()
+    c = CLIP(backend="torch")
     c.load_state_dict(sds["clip"], strict=True)
     out = c(torch.from_numpy(g["clip_tokens"]))
     assert (out - torch.from_numpy(g["clip_out"])).abs().max().item() < 2e-5

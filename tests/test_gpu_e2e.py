@@ -114,3 +114,23 @@ def test_native_vae_decoder_vs_reference():
     mae = ((a - b).abs().mean() / 2).item()
     G.log_metric(test="vae_native", size=64, rel_l2=rel, pixel_mae=mae, launches=nat.handle().last_launch_count)
     assert rel < 5e-3 and mae < 1e-3, f"64x64: rel L2 {rel:.2e}, pixel MAE {mae:.2e}"
+
+
+def test_native_clip_vs_reference():
+    """Native HIP CLIP text encoder (csrc/clip.hip) vs the reference CLIP's golden output (incl. causal mask,
+    quick-GELU, final LayerNorm) for two token rows."""
+    from pytorch_stable_diffusion_amd import model_loader
+    from pytorch_stable_diffusion_amd.clip import CLIP
+    g = H.load_npz("aux.npz")
+    sd = model_loader.synthetic_state_dicts(("clip",))["clip"]
+    c = CLIP(backend="native")
+    c.load_state_dict(sd, strict=True)
+    c.to(DEV)
+    tokens = torch.from_numpy(g["clip_tokens"]).to(DEV)
+    out = c(tokens).cpu()
+    ref = torch.from_numpy(g["clip_out"])
+    rel = H.rel_l2(out, ref)
+    G.log_metric(test="clip_native", rel_l2=rel, max_abs=(out - ref).abs().max().item(), launches=c.handle().last_launch_count)
+    assert rel < 3e-3, f"rel L2 {rel:.2e}"
+    one = c(tokens[:1]).cpu()                 # batch 1 == row 0 of the batch-2 call
+    assert H.rel_l2(one, out[:1]) < 1e-3
