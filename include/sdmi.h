@@ -111,6 +111,12 @@ int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int 
 void sdmi_vae_destroy(sdmi_vae* v);
 int sdmi_vae_decode(sdmi_vae* v, const float* latents_dev, float* image_dev, int batch, int h, int w, void* stream);
 int sdmi_vae_last_launch_count(const sdmi_vae* v);
+/* VAE encoder (reference sd/encoder.py:95-155; 104-entry state dict, keys "0.weight" ... "18.bias").
+ * image_dev: (B,3,H,W) NCHW fp32 in [-1,1]; noise_dev, latents_dev: (B,4,H/8,W/8) fp32.  Includes the asymmetric
+ * (0,1,0,1) pad before each stride-2 conv, the logvar clamp, the reparameterisation and the 0.18215 scale. */
+int sdmi_vae_encoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_vae** out);
+int sdmi_vae_encode(sdmi_vae* v, const float* image_dev, const float* noise_dev, float* latents_dev, int batch, int H, int W,
+                    void* stream);
 
 /* ---- CLIP text encoder (reference sd/clip.py:227-261) ------------------------------------------------
  * tensors: the 148-entry state dict of CLIP (sd/model_converter.py:885-1008,1031-1054).

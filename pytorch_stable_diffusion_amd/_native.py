@@ -58,6 +58,8 @@ _SIGNATURES = {
     "sdmi_vae_destroy": (None, [C.c_void_p]),
     "sdmi_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_vae_last_launch_count": (C.c_int, [C.c_void_p]),
+    "sdmi_vae_encoder_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdmi_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_clip_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sdmi_clip_destroy": (None, [C.c_void_p]),
     "sdmi_clip_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -158,14 +160,17 @@ def _tensor_descs(state: Dict[str, torch.Tensor]):
 
 
 class VaeDecoderHandle:
-    """Owns one native sdmi_vae (VAE decoder)."""
+    """Owns one native sdmi_vae (VAE decoder, or encoder with ``encoder=True``)."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], flags: int = FLAG_STREAM_F32):
+    def __init__(self, state: Dict[str, torch.Tensor], flags: int = FLAG_STREAM_F32, encoder: bool = False):
         lib = load()
         descs, keep = _tensor_descs(state)
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(lib.sdmi_vae_decoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_decoder_create")
+        if encoder:
+            check(lib.sdmi_vae_encoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_encoder_create")
+        else:
+            check(lib.sdmi_vae_decoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_decoder_create")
         del keep
         self._h, self._lib = h, lib
 
@@ -179,6 +184,15 @@ class VaeDecoderHandle:
             self.close()
         except Exception:
             pass
+
+    def encode(self, image: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        assert image.is_cuda and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3
+        image, noise = image.contiguous(), noise.to(image.device, torch.float32).contiguous()
+        b, _, hh, ww = image.shape
+        assert tuple(noise.shape) == (b, 4, hh // 8, ww // 8)
+        out = torch.empty((b, 4, hh // 8, ww // 8), dtype=torch.float32, device=image.device)
+        check(self._lib.sdmi_vae_encode(self._h, ptr(image), ptr(noise), ptr(out), b, hh, ww, cur_stream()), "sdmi_vae_encode")
+        return out
 
     def decode(self, latents: torch.Tensor) -> torch.Tensor:
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.dim() == 4 and latents.shape[1] == 4

@@ -147,6 +147,7 @@ int sdmi_launch_q4_reinterpret_add(const float* o, const void* x, int x_f32, voi
                                    int C, hipStream_t st);
 int sdmi_launch_clip_embed(const int64_t* tokens, const float* tok_emb, const float* pos_emb, float* out, f16* out16,
                            int rows, int T, int C, int vocab, hipStream_t st);
+int sdmi_launch_vae_sample(const float* mom, const float* noise, float* out, int B, size_t HW, hipStream_t st);
 int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* b, float* y, int B, int Cin, int Cout,
                                    size_t HW, float in_scale, hipStream_t st);
 int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,

@@ -252,7 +252,7 @@ struct Engine {
   int gemm(GemmArgs a) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks, a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad, a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan pl;
@@ -455,11 +455,15 @@ struct Engine {
     return SDMI_OK;
   }
 
-  int conv3(const ConvW& w, const Act& x, int stride, int ups, Act* y) {
+  // pad = 1: the UNet's / decoder's convs.  pad = 0 with stride 2 is the VAE encoder's asymmetric
+  // F.pad(x,(0,1,0,1)) + padding-0 conv (sd/encoder.py:120-122): taps past the right/bottom edge read zeros.
+  int conv3(const ConvW& w, const Act& x, int stride, int ups, Act* y, int pad = 1) {
     const int Hi = x.H << ups, Wi = x.W << ups;
-    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const int Ho = pad ? (Hi - 1) / stride + 1 : (Hi + 1 - 3) / stride + 1;
+    const int Wo = pad ? (Wi - 1) / stride + 1 : (Wi + 1 - 3) / stride + 1;
     TRY(new_act(x.B, Ho, Wo, w.O, true, y));
     GemmArgs a = base_args(x, nullptr, w, Ho, Wo, stride, ups);
+    a.pad = pad;
     set_out(a, *y);
     TRY(gemm(a));
     return SDMI_OK;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
   const int b = (int)(pix / ((size_t)W * H));
   const int C8 = Cin / 8;
   const int items = 9 * C8;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int it = lane; it < items; it += 64) {
     const int tap = it / C8, c8 = it - tap * C8;
     const int kh = tap / 3, kw = tap - kh * 3;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
     if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
     const f16x8 xv = *(const f16x8*)(x + (((size_t)b * H + ih) * W + iw) * Cin + c8 * 8);
 #pragma unroll
-    for (int co = 0; co < 4; ++co) {
+    for (int co = 0; co < 8; ++co) {
       if (co < Cout) {
         const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
 #pragma unroll
@@ -164,12 +164,12 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
     }
   }
 #pragma unroll
-  for (int co = 0; co < 4; ++co)
+  for (int co = 0; co < 8; ++co)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
   if (lane == 0) {
 #pragma unroll
-    for (int co = 0; co < 4; ++co)
+    for (int co = 0; co < 8; ++co)
       if (co < Cout) out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + bias[co];
   }
 }
@@ -306,6 +306,20 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int64_t* tokens, 
   }
 }
 
+// VAE encoder tail (sd/encoder.py:127-152): moments (B,8,h,w) NCHW -> mean, clamp(logvar,-30,20), z = mean +
+// sqrt(exp(logvar)) * noise, z *= 0.18215.   out (B,4,h,w) NCHW fp32.
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float* mom, const float* noise, float* out, int B, size_t HW) {
+  const size_t total = (size_t)B * 4 * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t n = i / (4 * HW), rem = i - n * 4 * HW;
+    const float mean = mom[n * 8 * HW + rem];
+    float lv = mom[n * 8 * HW + 4 * HW + rem];
+    lv = fminf(fmaxf(lv, -30.f), 20.f);
+    const float sd = sqrtf(expf(lv));
+    out[i] = (mean + sd * noise[i]) * 0.18215f;
+  }
+}
+
 inline int nblocks(size_t n, int per = 256, int cap = 4096) {
   size_t b = (n + per - 1) / per;
   if (b > (size_t)cap) b = cap;
@@ -364,7 +378,7 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
 
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, hipStream_t st) {
-  SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "final conv: Cin=%d Cout=%d", Cin, Cout);
+  SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "final conv: Cin=%d Cout=%d", Cin, Cout);
   const size_t npix = (size_t)B * H * W;
   hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
   SDMI_CHECK_HIP(hipGetLastError());
@@ -420,6 +434,12 @@ int sdmi_launch_clip_embed(const int64_t* tokens, const float* tok_emb, const fl
                            int rows, int T, int C, int vocab, hipStream_t st) {
   hipLaunchKernelGGL(clip_embed_kernel, dim3(nblocks((size_t)rows * C)), dim3(256), 0, st, tokens, tok_emb, pos_emb, out,
                      out16, rows, T, C, vocab);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_vae_sample(const float* mom, const float* noise, float* out, int B, size_t HW, hipStream_t st) {
+  hipLaunchKernelGGL(vae_sample_kernel, dim3(nblocks((size_t)B * 4 * HW)), dim3(256), 0, st, mom, noise, out, B, HW);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

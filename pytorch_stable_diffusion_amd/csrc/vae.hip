@@ -29,9 +29,26 @@ const std::vector<VaeOp>& decoder_ops() {
   return v;
 }
 
+const std::vector<VaeOp>& encoder_ops() {
+  // nn.Sequential positions of sd/encoder.py:8-94
+  static const std::vector<VaeOp> v = {
+      {7, 3, 128},                                   // 0: conv3x3 3->128 (stem kernel, NCHW fp32 image in)
+      {1, 128, 128}, {1, 128, 128}, {9, 128, 128},   // 3: stride-2 conv, asymmetric pad
+      {1, 128, 256}, {1, 256, 256}, {9, 256, 256},
+      {1, 256, 512}, {1, 512, 512}, {9, 512, 512},
+      {1, 512, 512}, {1, 512, 512}, {1, 512, 512}, {2, 512, 0}, {1, 512, 512},
+      {4, 512, 0}, {5, 0, 0}, {8, 512, 8},           // 15 GroupNorm, 16 SiLU, 17 conv3x3 512->8 (NCHW out)
+      {6, 8, 8},                                     // 18: conv1x1 8->8 (pointwise, NCHW)
+  };
+  return v;
+}
+
 }  // namespace
 
 struct sdmi_vae : Engine {
+  bool is_encoder = false;
+  int stem_cin = 4, stem_cout = 512;
+  float* mom = nullptr; float* mom2 = nullptr; size_t mom_elems = 0;
   float* w0 = nullptr; float* b0 = nullptr;          // 0: 1x1 conv 4->4 (fp32)
   float* stem_w = nullptr; float* stem_b = nullptr;  // 1: conv 4->512
   std::map<int, ResW> vres;
@@ -104,9 +121,10 @@ struct sdmi_vae : Engine {
 
 extern "C" {
 
-int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_vae** out) {
-  if (!tensors || !out || n_tensors <= 0) { sdmi_set_error("sdmi_vae_decoder_create: bad arguments"); return SDMI_EINVAL; }
+static int vae_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, bool encoder, sdmi_vae** out) {
+  if (!tensors || !out || n_tensors <= 0) { sdmi_set_error("sdmi_vae_create: bad arguments"); return SDMI_EINVAL; }
   sdmi_vae* v = new sdmi_vae();
+  v->is_encoder = encoder;
   v->flags = flags;
   v->stream_f32 = (flags & SDMI_FLAG_STREAM_F32) != 0;
   v->tune = (flags & SDMI_FLAG_NO_TUNE) == 0;
@@ -118,28 +136,30 @@ int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int 
   int rc;
   if ((rc = v->dmalloc(&v->zero, 4096)) != SDMI_OK) return fail(rc);
   if (hipMemset(v->zero, 0, 4096) != hipSuccess) return fail(SDMI_EHIP);
-  const auto& ops = decoder_ops();
+  const auto& ops = encoder ? encoder_ops() : decoder_ops();
   for (size_t i = 0; i < ops.size(); ++i) {
     const VaeOp& op = ops[i];
     const std::string p = std::to_string(i);
     switch (op.kind) {
-      case 6: {   // pointwise 4->4, kept fp32
+      case 6: {   // pointwise conv (4->4 / 8->8), kept fp32
         const sdmi_tensor_desc* t;
-        if ((rc = v->need(p + ".weight", &t, 4, {4, 4, 1, 1})) != SDMI_OK) return fail(rc);
-        if ((rc = v->dmalloc(&v->w0, 16 * 4)) != SDMI_OK) return fail(rc);
-        if ((rc = sdmi_launch_cast_any_f32(t->data_dev, t->dtype == SDMI_F32, v->w0, 16, v->st)) != SDMI_OK) return fail(rc);
-        if ((rc = v->load_vec(p + ".bias", 4, &v->b0)) != SDMI_OK) return fail(rc);
+        if ((rc = v->need(p + ".weight", &t, 4, {op.b, op.a, 1, 1})) != SDMI_OK) return fail(rc);
+        if ((rc = v->dmalloc(&v->w0, (size_t)op.a * op.b * 4)) != SDMI_OK) return fail(rc);
+        if ((rc = sdmi_launch_cast_any_f32(t->data_dev, t->dtype == SDMI_F32, v->w0, (size_t)op.a * op.b, v->st)) != SDMI_OK) return fail(rc);
+        if ((rc = v->load_vec(p + ".bias", op.b, &v->b0)) != SDMI_OK) return fail(rc);
         break;
       }
       case 7: {
         const sdmi_tensor_desc* t;
-        if ((rc = v->need(p + ".weight", &t, 4, {512, 4, 3, 3})) != SDMI_OK) return fail(rc);
-        if ((rc = v->dmalloc(&v->stem_w, (size_t)36 * 512 * 4)) != SDMI_OK) return fail(rc);
-        if ((rc = sdmi_launch_pack_stem(t->data_dev, t->dtype == SDMI_F32, v->stem_w, 512, 4, v->st)) != SDMI_OK) return fail(rc);
-        if ((rc = v->load_vec(p + ".bias", 512, &v->stem_b)) != SDMI_OK) return fail(rc);
+        if ((rc = v->need(p + ".weight", &t, 4, {op.b, op.a, 3, 3})) != SDMI_OK) return fail(rc);
+        if ((rc = v->dmalloc(&v->stem_w, (size_t)9 * op.a * op.b * 4)) != SDMI_OK) return fail(rc);
+        if ((rc = sdmi_launch_pack_stem(t->data_dev, t->dtype == SDMI_F32, v->stem_w, op.b, op.a, v->st)) != SDMI_OK) return fail(rc);
+        if ((rc = v->load_vec(p + ".bias", op.b, &v->stem_b)) != SDMI_OK) return fail(rc);
+        v->stem_cin = op.a; v->stem_cout = op.b;
         break;
       }
-      case 0: {
+      case 0:
+      case 9: {
         ConvW c;
         if ((rc = v->load_conv(p, op.b, op.a, 3, true, &c)) != SDMI_OK) return fail(rc);
         v->vconv[(int)i] = c;
@@ -179,6 +199,65 @@ int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int 
   return SDMI_OK;
 }
 
+int sdmi_vae_decoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_vae** out) {
+  return vae_create(tensors, n_tensors, flags, false, out);
+}
+int sdmi_vae_encoder_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_vae** out) {
+  return vae_create(tensors, n_tensors, flags, true, out);
+}
+
+// image_dev: (B,3,H,W) NCHW fp32 in [-1,1]; noise_dev: (B,4,H/8,W/8); latents_dev: (B,4,H/8,W/8) fp32
+// (reference: sd/encoder.py:95-155 incl. the asymmetric pad before each stride-2 conv and the x0.18215 scale).
+int sdmi_vae_encode(sdmi_vae* v, const float* image_dev, const float* noise_dev, float* latents_dev, int batch, int H, int W,
+                    void* stream) {
+  if (!v || !image_dev || !noise_dev || !latents_dev) { sdmi_set_error("vae_encode: null argument"); return SDMI_EINVAL; }
+  SDMI_REQUIRE(v->is_encoder, "vae_encode: handle is a decoder");
+  SDMI_REQUIRE(batch >= 1 && batch <= 8 && H % 64 == 0 && W % 64 == 0 && H >= 64 && W >= 64, "vae_encode: batch=%d H=%d W=%d unsupported", batch, H, W);
+  v->st = (hipStream_t)stream;
+  v->arena.off = 0;
+  v->launches = 0;
+  Act x;
+  TRY(v->new_act(batch, H, W, v->stem_cout, true, &x));
+  TRY(sdmi_launch_stem_conv(image_dev, batch, v->stem_w, v->stem_b, x.f ? (void*)x.f : (void*)x.h, x.f != nullptr,
+                            x.f ? x.h : nullptr, batch, H, W, v->stem_cout, v->stem_cin, v->st));
+  v->launches += 1;
+  const auto& ops = encoder_ops();
+  for (size_t i = 1; i < ops.size(); ++i) {
+    const VaeOp& op = ops[i];
+    Act y;
+    switch (op.kind) {
+      case 9:
+        TRY(v->conv3(v->vconv[(int)i], x, 2, 0, &y, 0));
+        x = y;
+        break;
+      case 1: {
+        const ResW& r = v->vres[(int)i];
+        TRY(v->res_block(r, x, nullptr, r.bias1, &y));
+        x = y;
+        break;
+      }
+      case 2:
+        TRY(v->vae_attn_block(v->vattn[(int)i], x, &y));
+        x = y;
+        break;
+      case 4: {
+        Act t;
+        TRY(v->groupnorm(x, nullptr, v->out_gn, 1e-5f, 1, &t));
+        const size_t n = (size_t)batch * 8 * x.H * x.W;
+        if (v->mom_elems < n) { TRY(v->dmalloc(&v->mom, n * 4)); TRY(v->dmalloc(&v->mom2, n * 4)); v->mom_elems = n; }
+        TRY(sdmi_launch_final_conv(t.h, v->out_conv.w, v->out_conv.bias, v->mom, x.B, x.H, x.W, x.C, 8, v->st));
+        TRY(sdmi_launch_conv1x1_nchw_small(v->mom, v->w0, v->b0, v->mom2, batch, 8, 8, (size_t)x.H * x.W, 1.0f, v->st));
+        TRY(sdmi_launch_vae_sample(v->mom2, noise_dev, latents_dev, batch, (size_t)x.H * x.W, v->st));
+        v->launches += 3;
+        return SDMI_OK;
+      }
+      default: break;
+    }
+  }
+  sdmi_set_error("vae_encode: malformed op list");
+  return SDMI_EINVAL;
+}
+
 void sdmi_vae_destroy(sdmi_vae* v) {
   if (v) { (void)hipDeviceSynchronize(); delete v; }
 }
@@ -187,6 +266,7 @@ void sdmi_vae_destroy(sdmi_vae* v) {
 // place on the caller's tensor, sd/decoder.py:364); image_dev: (B,3,8h,8w) NCHW fp32.
 int sdmi_vae_decode(sdmi_vae* v, const float* latents_dev, float* image_dev, int batch, int h, int w, void* stream) {
   if (!v || !latents_dev || !image_dev) { sdmi_set_error("vae_decode: null argument"); return SDMI_EINVAL; }
+  SDMI_REQUIRE(!v->is_encoder, "vae_decode: handle is an encoder");
   SDMI_REQUIRE(batch >= 1 && batch <= 8 && h >= 8 && w >= 8 && (h * w) % 64 == 0, "vae_decode: batch=%d h=%d w=%d unsupported", batch, h, w);
   v->st = (hipStream_t)stream;
   v->arena.off = 0;

@@ -1,10 +1,7 @@
 """VAE encoder / decoder with the reference's interface and weight ABI (sd/encoder.py:8-155,
-sd/decoder.py:7-374) -- INTERIM implementation.
-
-These are SURVEY 8f "next" rows, not the graded hot path: for now the arithmetic is delegated to
-PyTorch-ROCm ops on the GPU (rocBLAS/MIOpen) so that ``pipeline.generate`` runs end to end on the
-device.  The native port will reuse csrc/gemm.hip (implicit-GEMM conv) and csrc/norm.hip.
-The reference's behaviour is reproduced exactly, including its quirks:
+sd/decoder.py:7-374); SURVEY 8f "next" rows.  Default backend: native HIP (csrc/vae.hip, the UNet's
+implicit-GEMM / GroupNorm kernels plus a row-softmax).  The PyTorch-op restatement in this file is the explicit
+``backend="torch"`` path used by CPU unit tests.  The reference's behaviour is reproduced, including its quirks:
   Q3  VAE_AttentionBlock never applies its GroupNorm          (sd/decoder.py:31,34-73)
   Q4  ``x.transpose(-1, 2)`` is a no-op on a 3-D tensor and the (n, h*w, c) attention output is
       REINTERPRETED as (n, c, h, w) by ``view``                (sd/decoder.py:62,67)
@@ -154,12 +151,47 @@ class VAE_Decoder(_StateModule):
 
 
 class VAE_Encoder(_StateModule):
-    def __init__(self):
+    """``backend="native"`` (default): HIP kernels through libsdmi (csrc/vae.hip), cuda only, no fallback;
+    ``backend="torch"``: explicit PyTorch-op restatement (CPU unit tests)."""
+
+    def __init__(self, backend: str = "native"):
         super().__init__(arch.vae_encoder_manifest()[0])
+        if backend not in ("native", "torch"):
+            raise ValueError(f"unknown backend {backend}")
+        self.backend = backend
+        self._handle = None
+
+    def load_state_dict(self, state, strict: bool = True):
+        super().load_state_dict(state, strict)
+        self._drop()
+        return self
+
+    def to(self, device):
+        before = self._device
+        super().to(device)
+        if self._device != before:
+            self._drop()
+        return self
+
+    def _drop(self):
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = None
+
+    def handle(self):
+        from . import _native
+        if self._handle is None:
+            if self._device.type != "cuda":
+                raise RuntimeError("VAE_Encoder(backend='native') needs a cuda (ROCm) device; there is no CPU fallback")
+            with torch.cuda.device(self._device):
+                self._handle = _native.VaeDecoderHandle(self._state, encoder=True)
+        return self._handle
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) in [-1,1], noise (B,4,H/8,W/8) -> latents (sd/encoder.py:95-155)."""
+        if self.backend == "native":
+            return self.handle().encode(x.to(self._device, torch.float32), noise)
         x = _run(self._state, arch.VAE_ENCODER, x.to(self._device), pad_stride2=True)
         mean, log_variance = torch.chunk(x, 2, dim=1)
         log_variance = torch.clamp(log_variance, -30, 20)

@@ -23,7 +23,7 @@ def test_clip_vae_match_reference():
     img = d(lat_in)
     assert (img - torch.from_numpy(g["dec_out"])).abs().max().item() < 5e-5
     assert abs(float((lat_in / lat).mean()) - float(g["dec_inplace_ratio"])) < 1e-5     # in-place /= 0.18215
-    e = VAE_Encoder()
+    e = VAE_Encoder(backend="torch")
     e.load_state_dict(sds["encoder"], strict=True)
     x = H.seeded((1, 3, 64, 64), 302).clamp(-1, 1)
     z = e(x, H.seeded((1, 4, 8, 8), 303))

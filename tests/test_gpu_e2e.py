@@ -134,3 +134,30 @@ def test_native_clip_vs_reference():
     assert rel < 3e-3, f"rel L2 {rel:.2e}"
     one = c(tokens[:1]).cpu()                 # batch 1 == row 0 of the batch-2 call
     assert H.rel_l2(one, out[:1]) < 1e-3
+
+
+def test_native_vae_encoder_vs_reference():
+    """Native HIP VAE encoder (csrc/vae.hip) vs the reference encoder's golden latents (64x64 image) and vs the
+    torch-op restatement at 512x512 (asymmetric stride-2 padding, clamp/exp/sqrt reparameterisation, 0.18215)."""
+    from pytorch_stable_diffusion_amd import model_loader
+    from pytorch_stable_diffusion_amd.vae import VAE_Encoder
+    g = H.load_npz("aux.npz")
+    sd = model_loader.synthetic_state_dicts(("encoder",))["encoder"]
+    nat = VAE_Encoder(backend="native")
+    nat.load_state_dict(sd, strict=True)
+    nat.to(DEV)
+    x = H.seeded((1, 3, 64, 64), 302).clamp(-1, 1).to(DEV)
+    z = nat(x, H.seeded((1, 4, 8, 8), 303).to(DEV)).cpu()
+    ref = torch.from_numpy(g["enc_out"])
+    rel = H.rel_l2(z, ref)
+    G.log_metric(test="vae_enc_native", size=64, rel_l2=rel, max_abs=(z - ref).abs().max().item())
+    assert rel < 5e-3, f"64x64: rel L2 {rel:.2e}"
+    tor = VAE_Encoder(backend="torch")
+    tor.load_state_dict(sd, strict=True)
+    tor.to(DEV)
+    x2 = H.seeded((1, 3, 512, 512), 306).clamp(-1, 1).to(DEV)
+    n2 = H.seeded((1, 4, 64, 64), 307).to(DEV)
+    a, b = nat(x2, n2), tor(x2.clone(), n2)
+    rel = H.rel_l2(a.cpu(), b.cpu())
+    G.log_metric(test="vae_enc_native", size=512, rel_l2=rel)
+    assert rel < 5e-3, f"512x512: rel L2 {rel:.2e}"
