@@ -144,10 +144,19 @@ def main():
         ig = pr["igemm"]
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         scale = (hw / 64.0) ** 2
+        # HBM/fabric bytes per step of the same kernel family, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # passes around this command (FETCH_SIZE x2: gfx950 correction), committed under profiles/
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if hw == 64 and os.path.exists(tpath):
+            with open(tpath) as tf:
+                traffic = round(json.load(tf)["per_step"]["igemm"]["hbm_bytes"] / 1e9, 3)
+            traffic_src = "profiles/r01_hbm_traffic.json (GB per step, PMC passes of an earlier run of this command)"
         roof = {
-            "bound": "mfma", "kernel": "igemm_kernel (all conv3x3/conv1x1/linear launches of a step)",
+            "bound": "mfma", "kernel": "igemm_kernel + conv3_halo_kernel (all conv3x3/conv1x1/linear launches of a step)",
             "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": None,
+            "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "GB/step",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_step_GB": 1.62 + 2.6,
             "launches_per_step": ig["launches"] // nprof,
             "gflop_per_step": round(ig["flops"] / nprof / 1e9, 2),
             "ms_per_step": round(ig["ms"] / nprof, 3),
