@@ -114,16 +114,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   __syncthreads();
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, p.P);
-  const int items = (p1 - p0) * C8;
-  for (int it = tid; it < items; it += 256) {
-    const int px = p0 + it / C8, c8 = it % C8;
-    const int c = c8 * 8;
-    const bool second = c >= p.C0;
+  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 4 per thread
+  constexpr int IT = 4;
+  float v[IT][8];
+  int px_[IT], c_[IT];
+  bool ok[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {               // phase A: every load of this thread in flight at once
+    const int it = tid + k * 256;
+    ok[k] = it < items;
+    const int itc = ok[k] ? it : 0;
+    px_[k] = p0 + itc / C8;
+    c_[k] = (itc % C8) * 8;
+    const bool second = c_[k] >= p.C0;
     const void* base = second ? p.x1 : p.x0;
     const int cs = second ? p.C1 : p.C0;
-    const int cc = second ? c - p.C0 : c;
-    float v[8];
-    load8(base, p.in_f32, ((size_t)n * p.P + px) * cs + cc, v);
+    const int cc = second ? c_[k] - p.C0 : c_[k];
+    if (ok[k]) load8(base, p.in_f32, ((size_t)n * p.P + px_[k]) * cs + cc, v[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {               // phase B: normalise (+SiLU), convert, store
+    if (!ok[k]) continue;
+    const int c = c_[k];
     const f32x4 ga = *(const f32x4*)(p.gamma + c), gb = *(const f32x4*)(p.gamma + c + 4);
     const f32x4 ba = *(const f32x4*)(p.beta + c), bb = *(const f32x4*)(p.beta + c + 4);
     f16x8 o;
@@ -132,63 +144,77 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
       const int g = (c + e) / cpg;
       const float gam = e < 4 ? ga[e] : gb[e - 4];
       const float bet = e < 4 ? ba[e] : bb[e - 4];
-      float y = (v[e] - s_mean[g]) * s_rstd[g] * gam + bet;
+      float y = (v[k][e] - s_mean[g]) * s_rstd[g] * gam + bet;
       if (p.silu) y = y / (1.f + __expf(-y));
       o[e] = (f16)y;
     }
-    *(f16x8*)(p.y + ((size_t)n * p.P + px) * C + c) = o;
+    *(f16x8*)(p.y + ((size_t)n * p.P + px_[k]) * C + c) = o;
   }
 }
 
-// one wave per row; C in {320, 640, 1280} -> 40/80/160 chunks of 8 -> up to 3 chunks per lane
+// LayerNorm: each wave normalises LN_ROWS rows (all of their loads are issued before the first reduction);
+// C in {320, 640, 768, 1280} -> 40..160 chunks of 8 -> up to 3 chunks per lane.  Exact two-pass statistics.
+constexpr int LN_ROWS = 4;
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= p.M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  if (row0 >= p.M) return;
   const int C8 = p.C / 8;
-  float v[NCH][8];
-  float s = 0.f;
+  float v[LN_ROWS][NCH][8];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c8 = lane + i * 64;
-    if (c8 < C8) {
-      load8(p.x, p.in_f32, (size_t)row * p.C + c8 * 8, v[i]);
+  for (int rr = 0; rr < LN_ROWS; ++rr) {
+    const int row = min(row0 + rr, p.M - 1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
-    } else {
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + i * 64;
+      if (c8 < C8) load8(p.x, p.in_f32, (size_t)row * p.C + c8 * 8, v[rr][i]);
+      else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)p.C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c8 = lane + i * 64;
-    if (c8 < C8) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q / (float)p.C + p.eps);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c8 = lane + i * 64;
-    if (c8 < C8) {
-      const int c = c8 * 8;
-      f16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float yv = (v[i][e] - mean) * rstd * p.gamma[c + e] + p.beta[c + e];
-        o[e] = (f16)yv;
-        if (p.y32) p.y32[(size_t)row * p.C + c + e] = yv;
+        for (int e = 0; e < 8; ++e) v[rr][i][e] = 0.f;
       }
-      if (p.y) *(f16x8*)(p.y + (size_t)row * p.C + c) = o;
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < LN_ROWS; ++rr) {
+    const int row = row0 + rr;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[rr][i][e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + i * 64;
+      if (c8 < C8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[rr][i][e] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)p.C + p.eps);
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c8 = lane + i * 64;
+      if (c8 < C8) {
+        const int c = c8 * 8;
+        const f32x4 ga = *(const f32x4*)(p.gamma + c), gb = *(const f32x4*)(p.gamma + c + 4);
+        const f32x4 ba = *(const f32x4*)(p.beta + c), bb = *(const f32x4*)(p.beta + c + 4);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yv = (v[rr][i][e] - mean) * rstd * (e < 4 ? ga[e] : gb[e - 4]) + (e < 4 ? ba[e] : bb[e - 4]);
+          o[e] = (f16)yv;
+          if (p.y32) p.y32[(size_t)row * p.C + c + e] = yv;
+        }
+        if (p.y) *(f16x8*)(p.y + (size_t)row * p.C + c) = o;
+      }
     }
   }
 }
@@ -227,7 +253,7 @@ int sdmi_launch_layernorm(const LnArgs& a, hipStream_t st) {
   SDMI_REQUIRE(a.C % 8 == 0 && a.C <= 8 * 64 * 3, "layernorm: C=%d unsupported", a.C);
   SDMI_REQUIRE(a.x && (a.y || a.y32) && a.gamma && a.beta && a.M > 0, "layernorm: bad args");
   const int nch = (a.C / 8 + 63) / 64;
-  dim3 grid((a.M + 3) / 4), block(256);
+  dim3 grid((a.M + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), block(256);
   if (nch == 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, a);
   else if (nch == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, a);
