@@ -144,6 +144,9 @@ typedef struct sdmi_gemm_desc {
   void* out16;
   void* out_t; int nt0; int S; int ldt;
   int cfg; int ksplit;
+  /* optional extra 1x1 K-range after the ks*ks taps: x0 | x1 ([M][cx0], [M][cx1]) read at the output pixel;
+   * K = ks*ks*(c0+c1) + cx0 + cx1 (the ResBlock skip conv fused into conv_merged, sd/diffusion.py:143,209) */
+  const void* x0; const void* x1; int cx0, cx1;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */

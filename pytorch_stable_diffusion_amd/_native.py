@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                 ("out", C.c_void_p), ("out_f32", C.c_int), ("ldc", C.c_int),
                 ("out16", C.c_void_p),
                 ("out_t", C.c_void_p), ("nt0", C.c_int), ("S", C.c_int), ("ldt", C.c_int),
-                ("cfg", C.c_int), ("ksplit", C.c_int)]
+                ("cfg", C.c_int), ("ksplit", C.c_int),
+                ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None

@@ -51,6 +51,9 @@ struct GemmArgs {
   int C0, C1;          // channels per source (C1 = 0 when a1 == nullptr); multiples of 64
   int lda0, lda1;      // pixel (row) stride of each source in elements; 0 = dense (= C0 / C1)
   int ldw;             // row stride of w in elements; 0 = dense (= K)
+  // optional EXTRA 1x1 segment appended to K after the ks*ks taps (ResBlock skip conv fused into conv2):
+  // sources x0 | x1 (virtual concat) read at the output pixel, K += X0 + X1
+  const f16* x0; const f16* x1; int X0, X1, ldx0, ldx1;
   int Hs, Ws;          // stored source spatial dims
   int Ho, Wo;          // output spatial dims; M = B*Ho*Wo
   int ups;             // 1: nearest x2 upsample applied to the source on read

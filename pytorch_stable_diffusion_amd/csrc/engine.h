@@ -31,6 +31,8 @@ struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW {
   NormW gn1, gn2;
   ConvW conv1, conv2, skip;
+  f16* w2s = nullptr;      // conv2 | skip weights concatenated along K: [cout][9*cout + cin] (fused skip conv)
+  float* bias2s = nullptr; // conv2.bias + skip.bias
   ConvW time;             // linear_time [cout][1280]
   float* bias1 = nullptr; // conv_feature.bias + linear_time.bias (time-independent part)
   bool has_skip = false;
@@ -188,6 +190,17 @@ struct Engine {
     return SDMI_OK;
   }
 
+  // conv_merged and the 1x1 residual_layer share one accumulator: weights side by side along K, biases summed
+  int fuse_skip(ResW* r) {
+    const size_t k2 = (size_t)9 * r->cout, ks = (size_t)r->cin, kk = k2 + ks;
+    TRY(dmalloc(&r->w2s, (size_t)r->cout * kk * 2));
+    SDMI_CHECK_HIP(hipMemcpy2DAsync(r->w2s, kk * 2, r->conv2.w, k2 * 2, k2 * 2, r->cout, hipMemcpyDeviceToDevice, st));
+    SDMI_CHECK_HIP(hipMemcpy2DAsync(r->w2s + k2, kk * 2, r->skip.w, ks * 2, ks * 2, r->cout, hipMemcpyDeviceToDevice, st));
+    TRY(dmalloc(&r->bias2s, (size_t)r->cout * 4));
+    TRY(sdmi_launch_add_vec(r->conv2.bias, r->skip.bias, r->bias2s, r->cout, st));
+    weight_bytes += (int64_t)r->cout * kk * 2;
+    return SDMI_OK;
+  }
   int load_res(const std::string& p, int cin, int cout) {
     ResW r;
     r.cin = cin; r.cout = cout;
@@ -198,6 +211,7 @@ struct Engine {
     TRY(load_conv(p + ".conv_merged", cout, cout, 3, true, &r.conv2));
     r.has_skip = cin != cout;
     if (r.has_skip) TRY(load_conv(p + ".residual_layer", cout, cin, 1, true, &r.skip));
+    if (r.has_skip && cin % 64 == 0) TRY(fuse_skip(&r));
     TRY(dmalloc(&r.bias1, (size_t)cout * 4));
     TRY(sdmi_launch_add_vec(r.conv1.bias, r.time.bias, r.bias1, cout, st));
     r.time_off = time_total;
@@ -252,7 +266,7 @@ struct Engine {
   int gemm(GemmArgs a) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad, a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0), a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan pl;
@@ -379,6 +393,16 @@ struct Engine {
     TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
     TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
     GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+    if (r.has_skip && r.w2s) {
+      // skip 1x1 conv (sd/diffusion.py:143,209) as an extra K-range of conv_merged: one launch, no intermediate
+      a.x0 = x.h; a.X0 = x.C;
+      if (x1) { a.x1 = x1->h; a.X1 = x1->C; }
+      a.K += a.X0 + a.X1;
+      a.w = r.w2s; a.bias = r.bias2s;
+      set_out(a, *y);
+      TRY(gemm(a));
+      return SDMI_OK;
+    }
     if (r.has_skip) {
       TRY(new_act(x.B, x.H, x.W, r.cout, true, &sk));
       GemmArgs s = base_args(x, x1, r.skip, x.H, x.W, 1, 0);

@@ -241,29 +241,33 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   // segment state (wave-uniform)
   int tap = (kt0 * 64) / Cin;
   int seg_c = kt0 * 64 - tap * Cin;       // channel offset inside the concatenated Cin
+  if (tap >= p.ks * p.ks) { tap = p.ks * p.ks; seg_c = kt0 * 64 - tap * Cin; }   // inside the extra 1x1 segment
   int seg_left = 0;                       // K-steps left in the current segment
 
+  const int ntaps = p.ks * p.ks;
   auto open_segment = [&]() {
-    const int kh = (p.ks == 3) ? tap / 3 : 0;
-    const int kw = (p.ks == 3) ? tap - kh * 3 : 0;
-    const bool second = seg_c >= p.C0;
-    const f16* base = second ? p.a1 : p.a0;
-    const int cs = second ? p.C1 : p.C0;
-    const int ld = second ? p.lda1 : p.lda0;
-    const int cc = second ? seg_c - p.C0 : seg_c;
+    const bool extra = tap >= ntaps;                 // fused 1x1 skip segment: centre tap of x0 | x1
+    const int kh = extra ? p.pad : ((p.ks == 3) ? tap / 3 : 0);
+    const int kw = extra ? p.pad : ((p.ks == 3) ? tap - (tap / 3) * 3 : 0);
+    const int Ca = extra ? p.X0 : p.C0, Cb = extra ? p.X1 : p.C1;
+    const bool second = seg_c >= Ca;
+    const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
+    const int cs = second ? Cb : Ca;
+    const int ld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
+    const int cc = second ? seg_c - Ca : seg_c;
     seg_left = (cs - cc) >> 6;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
       const bool v = a_ok[i] && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
-      const int pix = a_pix0[i] + (ih >> p.ups) * p.Ws + (iw >> p.ups);
+      const int pix = a_pix0[i] + (extra ? ih * p.Ws + iw : (ih >> p.ups) * p.Ws + (iw >> p.ups));
       const f16* gr = base + ((size_t)pix * ld + cc + a_gch[i]);
       const f16* gz = p.zero + a_gch[i];
       a_ptr[i] = v ? gr : gz;
       a_inc[i] = v ? 64 : 0;
     }
     seg_c += seg_left << 6;
-    if (seg_c >= Cin) { seg_c = 0; ++tap; }
+    if (seg_c >= Ca + Cb) { seg_c = 0; ++tap; }
   };
 
   auto stage = [&](int buf) {
@@ -875,7 +879,7 @@ void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
 
 // halo-reuse kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image
 static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
-  if (a.ks != 3 || a.stride != 1 || a.pad != 1) return false;
+  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.X0 != 0) return false;
   if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
   if (a.Wo % 8 != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
   const int TH = c.BM / a.Wo;
@@ -912,7 +916,8 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.N % 8 == 0 && a.N > 0, "gemm: N=%d must be a positive multiple of 8", a.N);
   SDMI_REQUIRE(a.M > 0, "gemm: M=%d", a.M);
   SDMI_REQUIRE(a.C0 % 64 == 0 && a.C1 % 64 == 0 && a.C0 > 0, "gemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
-  SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1), "gemm: K=%d != ks^2*(C0+C1)", a.K);
+  SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1) + a.X0 + a.X1, "gemm: K=%d != ks^2*(C0+C1) + X0+X1", a.K);
+  SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");
   SDMI_REQUIRE(a.ks == 1 || a.ks == 3, "gemm: ks=%d", a.ks);
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");
   SDMI_REQUIRE(a.ldc % 8 == 0 && (!a.res || a.ldr % 8 == 0), "gemm: ldc/ldr must be multiples of 8");
@@ -930,6 +935,8 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   if (p.lda0 <= 0) p.lda0 = p.C0;
   if (p.lda1 <= 0) p.lda1 = p.C1;
   if (p.ldw <= 0) p.ldw = p.K;
+  if (p.ldx0 <= 0) p.ldx0 = p.X0;
+  if (p.ldx1 <= 0) p.ldx1 = p.X1;
   SDMI_REQUIRE(p.lda0 % 8 == 0 && p.lda1 % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
   if (p.ksplit < 1) p.ksplit = 1;
   if (p.ksplit > nkt) p.ksplit = nkt;

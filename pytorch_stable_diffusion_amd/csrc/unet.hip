@@ -429,6 +429,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.res = d->res; a.res_f32 = d->res_f32; a.ldr = d->ldr;
   a.out = d->out; a.out_f32 = d->out_f32; a.ldc = d->ldc; a.out16 = (f16*)d->out16;
   a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt;
+  a.x0 = (const f16*)d->x0; a.x1 = (const f16*)d->x1; a.X0 = d->cx0; a.X1 = d->cx1;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;

@@ -36,7 +36,7 @@ def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
 
 
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
-          out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False):
+          out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
@@ -62,6 +62,8 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.out_t = 0 if out_t is None else out_t.data_ptr()
     d.nt0, d.S, d.ldt = nt0, S, ldt
     d.cfg, d.ksplit = cfg, ksplit
+    d.x0 = 0 if x0 is None else x0.data_ptr(); d.cx0 = 0 if x0 is None else x0.shape[-1]
+    d.x1 = 0 if x1 is None else x1.data_ptr(); d.cx1 = 0 if x1 is None else x1.shape[-1]
     N.check(lib.sdmi_op_gemm(C.byref(d), N.cur_stream()), "sdmi_op_gemm")
     torch.cuda.synchronize()
     return (out, out16) if want16 else out

@@ -115,6 +115,35 @@ def test_conv_implicit_gemm(case):
         assert n_halo > 0, "no halo-reuse config ran on an eligible conv"
 
 
+@pytest.mark.parametrize("X0,X1,H,W", [(64, 0, 16, 16), (128, 64, 12, 12), (192, 128, 8, 8)])
+def test_conv_with_fused_skip_segment(X0, X1, H, W):
+    """conv_merged 3x3 + residual_layer 1x1 over the block input (two concat sources) in one accumulator
+    (sd/diffusion.py:143,194-209): K = 9*C + X0 + X1."""
+    B, Cm, Co = 2, 128, 192
+    g = torch.Generator().manual_seed(X0 + X1)
+    t = torch.randn((B, H, W, Cm), generator=g).half()
+    x0 = torch.randn((B, H, W, X0), generator=g).half()
+    x1 = torch.randn((B, H, W, X1), generator=g).half() if X1 else None
+    w3 = (torch.randn((Co, Cm, 3, 3), generator=g) / math.sqrt(9 * Cm)).half().float()
+    ws = (torch.randn((Co, X0 + X1, 1, 1), generator=g) / math.sqrt(X0 + X1)).half().float()
+    xs = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = _conv_ref(t, w3, 1, 0) + _conv_ref(xs, ws, 1, 0)
+    wp = torch.cat([G.pack_conv(w3.to(DEV)), G.pack_conv(ws.to(DEV))], 1).contiguous()
+    ran = 0
+    for cfg in [-1] + _cfgs():
+        for ksplit in (1, 2, 5):
+            try:
+                out = G.igemm(t.to(DEV), wp, B=B, Hs=H, Ws=W, Ho=H, Wo=W, ks=3, out_f32=True, cfg=cfg, ksplit=ksplit,
+                              x0=x0.to(DEV), x1=None if x1 is None else x1.to(DEV))
+            except ValueError as exc:       # halo-reuse kernels do not take the extra segment
+                assert "not applicable" in str(exc) or "LDS" in str(exc), exc
+                continue
+            ran += 1
+            err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
+            assert err < 2e-3, f"cfg {cfg} ksplit {ksplit}: max abs err {err}"
+    assert ran >= 3 * len(_plain_cfgs())
+
+
 def test_gemm_transposed_tail():
     """in_proj epilogue: columns [0,2C) row-major, columns [2C,3C) written as V^T[b][c][s]."""
     B, S, Cc = 2, 192, 128
