@@ -119,6 +119,7 @@ struct GnArgs {
   int nchunk;
 };
 int sdmi_gn_nchunk(int P);
+int sdmi_gn_launches(const GnArgs& a);
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st);
 
 struct LnArgs {

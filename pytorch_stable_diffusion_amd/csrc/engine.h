@@ -359,7 +359,7 @@ struct Engine {
     prof_begin(2, 0.0);
     TRY(sdmi_launch_groupnorm(g, st));
     prof_end();
-    launches += 2;
+    launches += sdmi_gn_launches(g);
     return SDMI_OK;
   }
   int layernorm(const Act& x, const NormW& w, Act* y) {

@@ -152,6 +152,68 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   }
 }
 
+// Single-launch GroupNorm for small feature maps: one 512-thread block per (group, image) keeps its whole
+// P x cpg slab in registers (<= MAXP channel pairs per thread), exact two-pass statistics, fixed-order
+// block reductions (deterministic).  Replaces stats+apply where the slab fits: one kernel boundary less.
+constexpr int GNF_NT = 512;
+template <int MAXP>
+__global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
+  __shared__ float s_w[2][GNF_NT / 64];
+  const int C = p.C0 + p.C1, cpg = C / 32, hp = cpg / 2;
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int total = p.P * hp;
+  f32x2 v[MAXP];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int slot = tid + i * GNF_NT;
+    v[i] = f32x2{0.f, 0.f};
+    if (slot < total) {
+      const int px = slot / hp, c = g * cpg + 2 * (slot - px * hp);
+      const bool second = c >= p.C0;
+      const void* base = second ? p.x1 : p.x0;
+      const int cs = second ? p.C1 : p.C0;
+      const size_t off = ((size_t)n * p.P + px) * cs + (second ? c - p.C0 : c);
+      if (p.in_f32) v[i] = *(const f32x2*)((const float*)base + off);
+      else { const f16x2 h = *(const f16x2*)((const f16*)base + off); v[i] = f32x2{(float)h[0], (float)h[1]}; }
+    }
+    s += v[i][0] + v[i][1];
+  }
+  auto block_sum = [&](float x, int which) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((tid & 63) == 0) s_w[which][tid >> 6] = x;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < GNF_NT / 64; ++w) t += s_w[which][w];
+    return t;
+  };
+  const float cnt = (float)cpg * (float)p.P;
+  const float mean = block_sum(s, 0) / cnt;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (tid + i * GNF_NT < total) {
+      const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
+      q += d0 * d0 + d1 * d1;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(q, 1) / cnt + p.eps);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int slot = tid + i * GNF_NT;
+    if (slot < total) {
+      const int px = slot / hp, c = g * cpg + 2 * (slot - px * hp);
+      const f32x2 ga = *(const f32x2*)(p.gamma + c), be = *(const f32x2*)(p.beta + c);
+      float y0 = (v[i][0] - mean) * rstd * ga[0] + be[0];
+      float y1 = (v[i][1] - mean) * rstd * ga[1] + be[1];
+      if (p.silu) { y0 = y0 / (1.f + __expf(-y0)); y1 = y1 / (1.f + __expf(-y1)); }
+      *(f16x2*)(p.y + ((size_t)n * p.P + px) * C + c) = f16x2{(f16)y0, (f16)y1};
+    }
+  }
+}
+
 // LayerNorm: each wave normalises LN_ROWS rows (all of their loads are issued before the first reduction);
 // C in {320, 640, 768, 1280} -> 40..160 chunks of 8 -> up to 3 chunks per lane.  Exact two-pass statistics.
 constexpr int LN_ROWS = 4;
@@ -228,12 +290,30 @@ int sdmi_gn_nchunk(int P) {
   return (P + ppc - 1) / ppc;
 }
 
+// 1 when the single-launch kernel takes this shape (slab of one group fits the block's registers), else 2
+int sdmi_gn_launches(const GnArgs& a) {
+  static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 256;   // measured: 64 blocks cannot pull larger maps fast enough
+  const int C = a.C0 + a.C1, cpg = C / 32;
+  const long pairs = ((long)a.P * (cpg / 2) + GNF_NT - 1) / GNF_NT;
+  return (cpg % 2 == 0 && a.C0 % 2 == 0 && a.P <= max_px && pairs <= 64) ? 1 : 2;
+}
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
   SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "groupnorm: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
   SDMI_REQUIRE(C / 8 <= 320, "groupnorm: C=%d too large (max 2560)", C);
   SDMI_REQUIRE(a.partial && a.y && a.x0 && a.gamma && a.beta, "groupnorm: null pointer");
   SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
+  if (sdmi_gn_launches(a) == 1) {
+    {
+      const long pairs = ((long)a.P * (C / 64) + GNF_NT - 1) / GNF_NT;
+      const dim3 grid(32, a.B), block(GNF_NT);
+      if (pairs <= 8) hipLaunchKernelGGL(gn_fused_kernel<8>, grid, block, 0, st, a);
+      else if (pairs <= 24) hipLaunchKernelGGL(gn_fused_kernel<24>, grid, block, 0, st, a);
+      else hipLaunchKernelGGL(gn_fused_kernel<64>, grid, block, 0, st, a);
+      SDMI_CHECK_HIP(hipGetLastError());
+      return SDMI_OK;
+    }
+  }
   const int C8 = C / 8;
   int PY = 256 / C8;
   if (PY < 1) PY = 1;

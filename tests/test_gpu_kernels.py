@@ -212,7 +212,8 @@ def test_flash_attention_large_logits():
 
 @pytest.mark.parametrize("C0,C1,P,in_f32,silu,eps", [(320, 0, 64, True, True, 1e-5), (640, 320, 256, False, True, 1e-5),
                                                      (1280, 640, 64, True, True, 1e-5), (320, 0, 4096, True, False, 1e-6),
-                                                     (1280, 1280, 64, False, True, 1e-5)])
+                                                     (1280, 1280, 64, False, True, 1e-5), (1280, 640, 1024, True, True, 1e-5),
+                                                     (640, 0, 1024, False, True, 1e-5), (640, 320, 4096, True, True, 1e-5)])
 def test_groupnorm(C0, C1, P, in_f32, silu, eps):
     B = 2
     Hh = int(math.isqrt(P))
