@@ -147,12 +147,26 @@ typedef struct sdmi_gemm_desc {
   /* optional extra 1x1 K-range after the ks*ks taps: x0 | x1 ([M][cx0], [M][cx1]) read at the output pixel;
    * K = ks*ks*(c0+c1) + cx0 + cx1 (the ResBlock skip conv fused into conv_merged, sd/diffusion.py:143,209) */
   const void* x0; const void* x1; int cx0, cx1;
+  /* LayerNorm folded around the GEMM (sd/diffusion.py:317-321,334-339,351-356).  Producer: rowstat != NULL ->
+   * the epilogue also writes per-row {sum, sum of squares} of the fp16 output over each n-tile to
+   * rowstat[(m*tiles_n + tn)*2] (tiles_n = ceil(N / tile width of cfg); ksplit 1, no out_t).  Consumer:
+   * ln_stat != NULL -> a0 is the raw (un-normalised) tensor, w/ln_g/bias come from sdmi_op_ln_fold_prep and
+   * out = rstd[m]*(acc - mean[m]*ln_g[n]) + bias[n], statistics summed from ln_stat[m][0..ln_ntn) over ln_c columns. */
+  float* rowstat;
+  const float* ln_stat; int ln_ntn; const float* ln_g; int ln_c; float ln_eps;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
 int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);
 const char* sdmi_gemm_config_name(int cfg);
+
+/* tile (rows, columns) of GEMM config cfg */
+void sdmi_gemm_config_dims(int cfg, int* bm, int* bn);
+/* Linear [N][C] (first N rows of w_dev) with a LayerNorm(gamma, beta) folded in: w_out = fp16(gamma (.) W),
+ * g_out[n] = sum_c w_out[n][c], h_out[n] = bias[n] + sum_c beta[c] W[n][c]  (bias may be NULL). */
+int sdmi_op_ln_fold_prep(const void* w_dev, int w_dtype, const float* gamma, const float* beta, const float* bias,
+                         void* w_out, float* g_out, float* h_out, int N, int C, void* stream);
 
 /* PyTorch OIHW (fp32/fp16) -> packed [o < o_keep][kh][kw][I] fp16. */
 int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream);

@@ -31,7 +31,9 @@ class GemmDesc(C.Structure):
                 ("out16", C.c_void_p),
                 ("out_t", C.c_void_p), ("nt0", C.c_int), ("S", C.c_int), ("ldt", C.c_int),
                 ("cfg", C.c_int), ("ksplit", C.c_int),
-                ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int)]
+                ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int),
+                ("rowstat", C.c_void_p), ("ln_stat", C.c_void_p), ("ln_ntn", C.c_int), ("ln_g", C.c_void_p),
+                ("ln_c", C.c_int), ("ln_eps", C.c_float)]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -76,6 +78,9 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "sdmi_op_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_void_p, C.c_void_p]),
+    "sdmi_gemm_config_dims": (None, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdmi_op_ln_fold_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())

@@ -80,11 +80,19 @@ struct GemmArgs {
   int ksplit;
   int ksteps_per;
   int act;             // epilogue activation after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170)
+  // LayerNorm folded around the GEMM (sd/diffusion.py:317,334,351 feeding 321/339/356):
+  //  producer side: rowstat != null -> the epilogue also writes per-row {sum, sum of squares} of the fp16 output
+  //    over this n-tile to rowstat[(m*tiles_n + tn)*2] (ksplit == 1, no transposed tail);
+  //  consumer side: ln_stat != null -> A is the RAW stream, w = gamma (.) W, and the epilogue applies
+  //    out = rstd[m]*(acc - mean[m]*ln_g[n]) + bias[n], mean/rstd from ln_stat[m][0..ln_ntn) over ln_C columns.
+  float* rowstat;
+  const float* ln_stat; int ln_ntn; const float* ln_g; int ln_C; float ln_eps;
 };
 
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
+int sdmi_gemm_num_plain_cfgs(void);   // configs [0, n) are igemm_kernel tiles; the rest are halo-reuse conv kernels
 void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn);
 bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg);
 size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int cfg, int ksplit);
@@ -157,4 +165,6 @@ int sdmi_launch_conv1x1_nchw_small(const float* x, const float* w, const float* 
 int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* latents, const float* noise,
                          const float* coef, size_t n, float* eps_out, hipStream_t st);
 int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st);
+int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, const float* beta, const float* bias,
+                            f16* w_out, float* g_out, float* h_out, int N, int C, hipStream_t st);
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);

@@ -38,9 +38,15 @@ struct ResW {
   bool has_skip = false;
   int cin = 0, cout = 0, time_off = 0;
 };
+// Linear with the preceding LayerNorm folded in: w = gamma (.) W (fp16), g[n] = sum_c w[n][c], h[n] = b[n] + sum_c beta[c] W[n][c]
+struct FoldW { f16* w = nullptr; float* g = nullptr; float* h = nullptr; };
+// per-row {sum, sum of squares} partials a GEMM epilogue left behind for the LayerNorm of its output
+struct RowStat { const float* ptr = nullptr; int ntn = 0; };
+
 struct AttnW {
   NormW gn, ln1, ln2, ln3;
   ConvW conv_in, conv_out, in_proj, out1, q, k, v, out2, g1, g2;
+  FoldW in_proj_f, q_f, g1_f;      // layernorm_1/2/3 folded into in_proj / q_proj / linear_geglu_1
   int C = 0, dh = 0, ctx_idx = 0;
 };
 struct Act {
@@ -62,7 +68,7 @@ struct Arena {
 };
 
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;
-struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; };
+struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; long calls = 0; double flops = 0.0; };
 
 struct Engine {
   int flags = 0;
@@ -220,6 +226,18 @@ struct Engine {
     res_order.push_back(p);
     return SDMI_OK;
   }
+  // first N rows of Linear `p` ([O][C], O >= N) with LayerNorm `ln` folded in
+  int load_fold(const std::string& p, int N, int C, const NormW& ln, const float* bias, FoldW* f) {
+    const sdmi_tensor_desc* t;
+    TRY(need(p + ".weight", &t, 2, {-1, C}));
+    if (t->shape[0] < N) { sdmi_set_error("tensor '%s.weight': %lld rows, need %d", p.c_str(), (long long)t->shape[0], N); return SDMI_EINVAL; }
+    TRY(dmalloc(&f->w, (size_t)N * C * 2));
+    TRY(dmalloc(&f->g, (size_t)N * 4));
+    TRY(dmalloc(&f->h, (size_t)N * 4));
+    TRY(sdmi_launch_ln_fold_prep(t->data_dev, t->dtype == SDMI_F32, ln.gamma, ln.beta, bias, f->w, f->g, f->h, N, C, st));
+    weight_bytes += (int64_t)N * C * 2 + (int64_t)N * 8;
+    return SDMI_OK;
+  }
   int load_attn(const std::string& p, int heads, int dh) {
     AttnW a;
     const int C = heads * dh;
@@ -239,6 +257,9 @@ struct Engine {
     TRY(load_conv(p + ".linear_geglu_1", 8 * C, C, 1, true, &a.g1, 4 * C));
     TRY(load_conv(p + ".linear_geglu_2", C, 4 * C, 1, true, &a.g2));
     TRY(load_conv(p + ".conv_output", C, C, 1, true, &a.conv_out));
+    TRY(load_fold(p + ".attention_1.in_proj", 3 * C, C, a.ln1, nullptr, &a.in_proj_f));
+    TRY(load_fold(p + ".attention_2.q_proj", C, C, a.ln2, nullptr, &a.q_f));
+    TRY(load_fold(p + ".linear_geglu_1", 4 * C, C, a.ln3, a.g1.bias, &a.g1_f));
     a.ctx_idx = (int)attn_order.size();
     attn[p] = a;
     attn_order.push_back(p);
@@ -263,10 +284,11 @@ struct Engine {
   }
 
   // ---- GEMM with per-shape plan -----------------------------------------------------------------
-  int gemm(GemmArgs a) {
+  // rs != null: ask the epilogue for LayerNorm row statistics of the output (granted when the plan has ksplit == 1)
+  int gemm(GemmArgs a, RowStat* rs = nullptr) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0), a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr), a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan pl;
@@ -274,12 +296,42 @@ struct Engine {
       it = plans.emplace(key, pl).first;
     }
     a.ksplit = it->second.ksplit;
+    if (rs) {
+      static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
+      rs->ptr = nullptr;
+      if (!no_fold && a.ksplit == 1 && !a.outT && it->second.cfg >= 0 && it->second.cfg < sdmi_gemm_num_plain_cfgs()) {
+        int bm, bn;
+        sdmi_gemm_cfg_dims(it->second.cfg, &bm, &bn);
+        const int ntn = (a.N + bn - 1) / bn;
+        float* buf = (float*)arena.alloc((size_t)a.M * ntn * 8);
+        if (!buf) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
+        a.rowstat = buf;
+        rs->ptr = buf; rs->ntn = ntn;
+      }
+    }
+    it->second.calls += 1;
+    it->second.flops = 2.0 * a.M * a.N * a.K;
     const int nl = a.ksplit > 1 ? 2 : 1;
     prof_begin(0, 2.0 * a.M * a.N * a.K);
     TRY(sdmi_launch_gemm(a, it->second.cfg, st));
     prof_end();
     launches += nl;
     return SDMI_OK;
+  }
+
+  // SDMI_TUNE_LOG: per-shape plan table (isolated tuned time x calls) on stderr, e.g. at destroy
+  void plan_report(const char* who) const {
+    if (!getenv("SDMI_TUNE_LOG")) return;
+    double tot = 0.0;
+    for (const auto& kv : plans) tot += (double)kv.second.us * kv.second.calls;
+    fprintf(stderr, "[sdmi plans] %s: %zu shapes, sum(tuned us x calls) = %.1f us\n", who, plans.size(), tot);
+    for (const auto& kv : plans) {
+      const Plan& pl = kv.second;
+      if (pl.calls == 0 || pl.cfg < 0) continue;
+      fprintf(stderr, "[sdmi plans]   M=%-5d N=%-5d K=%-5d ks=%d s=%d up=%d  %-18s split %2d  %7.1f us x %4ld = %8.1f us  %6.1f TF/s  (%.2f GFLOP)\n",
+              std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first) & 15,
+              std::get<4>(kv.first), std::get<5>(kv.first), sdmi_gemm_cfg_name(pl.cfg), pl.ksplit, pl.us, pl.calls, pl.us * pl.calls, pl.flops / pl.us * 1e-6, pl.flops * 1e-9);
+    }
   }
 
   int tune_gemm(const GemmArgs& a0, Plan* best) {
@@ -296,6 +348,7 @@ struct Engine {
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
         if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
+        if (ks > 1 && a0.ln_stat) continue;          // the folded epilogue lives in the one-pass path only
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
@@ -432,6 +485,13 @@ struct Engine {
     return SDMI_OK;
   }
 
+  // LayerNorm -> Linear with the norm folded into the GEMM: A = raw stream (fp16 shadow), row statistics from the
+  // producer's epilogue, out = rstd*(x W'^T - mean*g) + h.  No LayerNorm launch, no normalised intermediate.
+  static void fold_ln(GemmArgs& a, const FoldW& f, const RowStat& rs, int C) {
+    a.w = f.w; a.bias = f.h;
+    a.ln_stat = rs.ptr; a.ln_ntn = rs.ntn; a.ln_g = f.g; a.ln_C = C; a.ln_eps = 1e-5f;
+  }
+
   // UNET_AttentionBlock (sd/diffusion.py:271-381)
   int attn_block(const AttnW& w, const Act& x, Act* y) {
     if (x.C != w.C) { sdmi_set_error("attn_block: C %d vs %d", x.C, w.C); return SDMI_EINVAL; }
@@ -444,15 +504,17 @@ struct Engine {
     Act t0, s0, u, qk, ao, s1, q2, s2, g, s3;
     TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
     TRY(new_act(B, x.H, x.W, C, true, &s0));
-    { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a)); }
+    RowStat rs;
+    { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
     // self-attention
-    TRY(layernorm(s0, w.ln1, &u));
+    if (!rs.ptr) TRY(layernorm(s0, w.ln1, &u));
     TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
     if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
     if (Spad != S) { SDMI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)B * C * Spad * 2, st)); launches += 1; }
     {
-      GemmArgs a = base_args(u, nullptr, w.in_proj, x.H, x.W, 1, 0);
+      GemmArgs a = base_args(rs.ptr ? s0 : u, nullptr, w.in_proj, x.H, x.W, 1, 0);
+      if (rs.ptr) fold_ln(a, w.in_proj_f, rs, C);
       a.out = qk.h; a.ldc = 2 * C;
       a.outT = vt; a.nt0 = 2 * C; a.S = S; a.ldt = Spad;
       TRY(gemm(a));
@@ -460,18 +522,28 @@ struct Engine {
     TRY(new_act(B, x.H, x.W, C, false, &ao));
     TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
     TRY(new_act(B, x.H, x.W, C, true, &s1));
-    { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a)); }
+    { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a, &rs)); }
     // cross-attention (K/V hoisted in set_context)
-    TRY(layernorm(s1, w.ln2, &u));
+    if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
     TRY(new_act(B, x.H, x.W, C, false, &q2));
-    { GemmArgs a = base_args(u, nullptr, w.q, x.H, x.W, 1, 0); a.out = q2.h; a.ldc = C; TRY(gemm(a)); }
+    {
+      GemmArgs a = base_args(rs.ptr ? s1 : u, nullptr, w.q, x.H, x.W, 1, 0);
+      if (rs.ptr) fold_ln(a, w.q_f, rs, C);
+      a.out = q2.h; a.ldc = C;
+      TRY(gemm(a));
+    }
     TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
     TRY(new_act(B, x.H, x.W, C, true, &s2));
-    { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a)); }
+    { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
     // feed-forward: first half of linear_geglu_1 only (reference discards the gate)
-    TRY(layernorm(s2, w.ln3, &u));
+    if (!rs.ptr) TRY(layernorm(s2, w.ln3, &u));
     TRY(new_act(B, x.H, x.W, 4 * C, false, &g));
-    { GemmArgs a = base_args(u, nullptr, w.g1, x.H, x.W, 1, 0); a.out = g.h; a.ldc = 4 * C; TRY(gemm(a)); }
+    {
+      GemmArgs a = base_args(rs.ptr ? s2 : u, nullptr, w.g1, x.H, x.W, 1, 0);
+      if (rs.ptr) fold_ln(a, w.g1_f, rs, C);
+      a.out = g.h; a.ldc = 4 * C;
+      TRY(gemm(a));
+    }
     TRY(new_act(B, x.H, x.W, C, true, &s3));
     { GemmArgs a = base_args(g, nullptr, w.g2, x.H, x.W, 1, 0); set_res(a, s2); set_out(a, s3); TRY(gemm(a)); }
     TRY(new_act(B, x.H, x.W, C, true, y));

@@ -51,7 +51,8 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
 // V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
 template <int BM, int BN, int NT>
-__device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, int m0, int n0, int kz, int tid) {
+__device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, int m0, int n0, int kz, int tid,
+                                           const float* s_ln = nullptr, int tn = 0, int tiles_n = 1) {
   if (p.ksplit > 1) {
     float* slab = p.slab + (size_t)kz * p.M * p.N;
     for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
@@ -69,7 +70,9 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     // it in this loop).  Phase 2 reads the tile from LDS, adds, converts and stores.
     constexpr int ITEMS = (BM * (BN / 8) + NT - 1) / NT;
     f32x4 r0[ITEMS], r1[ITEMS], b0[ITEMS], b1[ITEMS];
+    f32x4 g0[ITEMS], g1[ITEMS];            // LayerNorm fold: column sums of gamma (.) W
     f16x8 rh[ITEMS];
+    const bool fold = p.ln_stat != nullptr;
     bool ok[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -83,6 +86,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       for (int e = 0; e < 8; ++e) rh[it][e] = (f16)0.f;
       if (ok[it]) {
         if (p.bias) { b0[it] = *(const f32x4*)(p.bias + n); b1[it] = *(const f32x4*)(p.bias + n + 4); }
+        if (fold) { g0[it] = *(const f32x4*)(p.ln_g + n); g1[it] = *(const f32x4*)(p.ln_g + n + 4); }
         if (p.res) {
           if (p.res_f32) {
             const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
@@ -96,40 +100,58 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-      if (!ok[it]) continue;
       const int idx = it * NT + tid;
       const int row = idx / (BN / 8), c8 = idx % (BN / 8);
       const int m = m0 + row, n = n0 + c8 * 8;
-      const f32x4 v0 = *(const f32x4*)(Cs + row * BN + c8 * 8);
-      const f32x4 v1 = *(const f32x4*)(Cs + row * BN + c8 * 8 + 4);
-      float v[8];
+      float rs = 0.f, rq = 0.f;
+      if (ok[it]) {
+        const f32x4 v0 = *(const f32x4*)(Cs + row * BN + c8 * 8);
+        const f32x4 v1 = *(const f32x4*)(Cs + row * BN + c8 * 8 + 4);
+        float v[8];
+        if (fold) {
+          const float mean = s_ln[2 * row], rstd = s_ln[2 * row + 1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = v0[e] + b0[it][e];
-        v[4 + e] = v1[e] + b1[it][e];
+          for (int e = 0; e < 4; ++e) {
+            v[e] = rstd * (v0[e] - mean * g0[it][e]) + b0[it][e];
+            v[4 + e] = rstd * (v1[e] - mean * g1[it][e]) + b1[it][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = v0[e] + b0[it][e];
+            v[4 + e] = v1[e] + b1[it][e];
+          }
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += r0[it][e] + (float)rh[it][e];
+          v[4 + e] += r1[it][e] + (float)rh[it][4 + e];
+        }
+        f16x8 o16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o16[e] = (f16)v[e];
+        if (p.out_f32) {
+          float* op = (float*)p.out + (size_t)m * p.ldc + n;
+          f32x4 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+          *(f32x4*)op = o0;
+          *(f32x4*)(op + 4) = o1;
+          if (p.out16) *(f16x8*)(p.out16 + (size_t)m * p.ldc + n) = o16;
+        } else {
+          *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float x = (float)o16[e]; rs += x; rq += x * x; }
       }
-      if (p.act == 1) {
+      if (p.rowstat) {       // wave-uniform branch; the BN/8 lanes of one row are consecutive and aligned
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += r0[it][e] + (float)rh[it][e];
-        v[4 + e] += r1[it][e] + (float)rh[it][4 + e];
-      }
-      f16x8 o16;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o16[e] = (f16)v[e];
-      if (p.out_f32) {
-        float* op = (float*)p.out + (size_t)m * p.ldc + n;
-        f32x4 o0, o1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
-        *(f32x4*)op = o0;
-        *(f32x4*)(op + 4) = o1;
-        if (p.out16) *(f16x8*)(p.out16 + (size_t)m * p.ldc + n) = o16;
-      } else {
-        *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
+        for (int o = 1; o < BN / 8; o <<= 1) { rs += __shfl_xor(rs, o); rq += __shfl_xor(rq, o); }
+        if (c8 == 0 && idx < BM * (BN / 8) && m < p.M) *(f32x2*)(p.rowstat + ((size_t)m * tiles_n + tn) * 2) = f32x2{rs, rq};
       }
     }
   } else {
@@ -142,7 +164,11 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       const float bv = p.bias ? p.bias[n] : 0.f;
       f16x8 o16;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o16[e] = (f16)(Cs[(r8 * 8 + e) * BN + col] + bv);
+      for (int e = 0; e < 8; ++e) {
+        float v = Cs[(r8 * 8 + e) * BN + col];
+        if (p.ln_stat) v = s_ln[2 * (r8 * 8 + e) + 1] * (v - s_ln[2 * (r8 * 8 + e)] * p.ln_g[n]);
+        o16[e] = (f16)(v + bv);
+      }
       if ((p.S & 7) == 0) {
         const int b = m / p.S, s = m - b * p.S;
         *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
@@ -199,6 +225,22 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   const int nkt = p.K >> 6;
   const int kt0 = kz * p.ksteps_per;
   const int kt1 = min(kt0 + p.ksteps_per, nkt);
+
+  // LayerNorm fold: mean / rstd of this tile's rows from the producer's per-n-tile partial sums.  Issued first so
+  // the loads overlap the main loop; read after the epilogue barrier.
+  __shared__ float s_ln[2 * BM];
+  if (p.ln_stat != nullptr && tid < BM) {
+    const int m = min(m0 + tid, p.M - 1);
+    const f32x2* sp = (const f32x2*)p.ln_stat + (size_t)m * p.ln_ntn;
+    float su = 0.f, sq = 0.f;
+    for (int j = 0; j < p.ln_ntn; ++j) { const f32x2 t = sp[j]; su += t[0]; sq += t[1]; }
+    const float inv = 1.f / (float)p.ln_C;
+    const float mean = su * inv;
+    float var = sq * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_ln[2 * tid] = mean;
+    s_ln[2 * tid + 1] = rsqrtf(var + p.ln_eps);
+  }
 
   const int Cin = p.C0 + p.C1;
   const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
@@ -466,7 +508,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       }
   __syncthreads();
 
-  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
+  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid, s_ln, tn, tiles_n);
 #ifdef SDMI_CLK_PROBE
   if (tid == 0 && blockIdx.x < 2048) {
     g_clk_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk_t0;
@@ -871,6 +913,7 @@ const char* sdmi_gemm_cfg_name(int cfg) {
   return "?";
 }
 
+int sdmi_gemm_num_plain_cfgs(void) { return kNumCfgs; }
 void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
   const CfgInfo& c = cfg < kNumCfgs ? kCfgs[cfg] : kHaloCfgs[cfg - kNumCfgs];
   *bm = c.BM;
@@ -879,7 +922,7 @@ void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
 
 // halo-reuse kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image
 static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
-  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.X0 != 0) return false;
+  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.X0 != 0 || a.rowstat || a.ln_stat) return false;
   if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
   if (a.Wo % 8 != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
   const int TH = c.BM / a.Wo;
@@ -917,6 +960,8 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.M > 0, "gemm: M=%d", a.M);
   SDMI_REQUIRE(a.C0 % 64 == 0 && a.C1 % 64 == 0 && a.C0 > 0, "gemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
   SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1) + a.X0 + a.X1, "gemm: K=%d != ks^2*(C0+C1) + X0+X1", a.K);
+  SDMI_REQUIRE(!a.rowstat || (a.ksplit <= 1 && !a.outT), "gemm: row statistics need ksplit == 1 and no transposed tail");
+  SDMI_REQUIRE(!a.ln_stat || (a.ksplit <= 1 && a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && !a.res), "gemm: bad LayerNorm-fold arguments");
   SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");
   SDMI_REQUIRE(a.ks == 1 || a.ks == 3, "gemm: ks=%d", a.ks);
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");

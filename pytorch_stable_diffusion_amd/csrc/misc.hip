@@ -327,6 +327,30 @@ inline int nblocks(size_t n, int per = 256, int cap = 4096) {
   return (int)b;
 }
 
+// LayerNorm folded into the following Linear (y = LN(x) W^T + b):  W' = gamma (.) W (fp16), g[n] = sum_c W'[n][c]
+// (of the ROUNDED values, so that mean * g cancels exactly what the MFMA accumulates), h[n] = b[n] + sum_c beta[c] W[n][c].
+__global__ __launch_bounds__(256) void ln_fold_prep_kernel(const void* w_src, int is_f32, const float* gamma, const float* beta,
+                                                            const float* bias, f16* w_out, float* g_out, float* h_out, int C) {
+  __shared__ float s_red[2][4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float gs = 0.f, hs = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float w = is_f32 ? ((const float*)w_src)[(size_t)n * C + c] : (float)((const f16*)w_src)[(size_t)n * C + c];
+    const f16 wf = (f16)(gamma[c] * w);
+    w_out[(size_t)n * C + c] = wf;
+    gs += (float)wf;
+    hs += beta[c] * w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o); hs += __shfl_xor(hs, o); }
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = gs; s_red[1][tid >> 6] = hs; }
+  __syncthreads();
+  if (tid == 0) {
+    g_out[n] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    h_out[n] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3] + (bias ? bias[n] : 0.f);
+  }
+}
+
 }  // namespace
 
 int sdmi_launch_cast_f32_f16(const float* x, f16* y, size_t n, hipStream_t st) {
@@ -440,6 +464,14 @@ int sdmi_launch_clip_embed(const int64_t* tokens, const float* tok_emb, const fl
 
 int sdmi_launch_vae_sample(const float* mom, const float* noise, float* out, int B, size_t HW, hipStream_t st) {
   hipLaunchKernelGGL(vae_sample_kernel, dim3(nblocks((size_t)B * 4 * HW)), dim3(256), 0, st, mom, noise, out, B, HW);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, const float* beta, const float* bias,
+                            f16* w_out, float* g_out, float* h_out, int N, int C, hipStream_t st) {
+  SDMI_REQUIRE(w_src && gamma && beta && w_out && g_out && h_out && N > 0 && C > 0, "ln_fold_prep: bad arguments");
+  hipLaunchKernelGGL(ln_fold_prep_kernel, dim3(N), dim3(256), 0, st, w_src, is_f32, gamma, beta, bias, w_out, g_out, h_out, C);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

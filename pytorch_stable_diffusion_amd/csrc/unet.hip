@@ -228,7 +228,7 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
 }
 
 void sdmi_unet_destroy(sdmi_unet* u) {
-  if (u) { (void)hipDeviceSynchronize(); delete u; }
+  if (u) { (void)hipDeviceSynchronize(); u->plan_report("unet"); delete u; }
 }
 
 int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_tokens, void* stream) {
@@ -430,6 +430,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.out = d->out; a.out_f32 = d->out_f32; a.ldc = d->ldc; a.out16 = (f16*)d->out16;
   a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt;
   a.x0 = (const f16*)d->x0; a.x1 = (const f16*)d->x1; a.X0 = d->cx0; a.X1 = d->cx1;
+  a.rowstat = d->rowstat; a.ln_stat = d->ln_stat; a.ln_ntn = d->ln_ntn; a.ln_g = d->ln_g; a.ln_C = d->ln_c; a.ln_eps = d->ln_eps;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
@@ -456,6 +457,12 @@ int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void
 }
 int sdmi_gemm_num_configs(void) { return sdmi_gemm_num_cfgs(); }
 const char* sdmi_gemm_config_name(int cfg) { return sdmi_gemm_cfg_name(cfg); }
+
+void sdmi_gemm_config_dims(int cfg, int* bm, int* bn) { sdmi_gemm_cfg_dims(cfg, bm, bn); }
+int sdmi_op_ln_fold_prep(const void* w_dev, int w_dtype, const float* gamma, const float* beta, const float* bias,
+                         void* w_out, float* g_out, float* h_out, int N, int C, void* stream) {
+  return sdmi_launch_ln_fold_prep(w_dev, w_dtype == SDMI_F32, gamma, beta, bias, (f16*)w_out, g_out, h_out, N, C, (hipStream_t)stream);
+}
 
 int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream) {
   return sdmi_launch_pack_conv(w_dev, w_dtype == SDMI_F32, (f16*)out_dev, O, I, ks, o_keep, (hipStream_t)stream);

@@ -36,7 +36,8 @@ def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
 
 
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
-          out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None):
+          out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
+          rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
@@ -64,6 +65,9 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.cfg, d.ksplit = cfg, ksplit
     d.x0 = 0 if x0 is None else x0.data_ptr(); d.cx0 = 0 if x0 is None else x0.shape[-1]
     d.x1 = 0 if x1 is None else x1.data_ptr(); d.cx1 = 0 if x1 is None else x1.shape[-1]
+    d.rowstat = 0 if rowstat is None else rowstat.data_ptr()
+    if ln_stat is not None:
+        d.ln_stat, d.ln_ntn, d.ln_g, d.ln_c, d.ln_eps = ln_stat.data_ptr(), ln_stat.shape[1], ln_g.data_ptr(), ln_c, ln_eps
     N.check(lib.sdmi_op_gemm(C.byref(d), N.cur_stream()), "sdmi_op_gemm")
     torch.cuda.synchronize()
     return (out, out16) if want16 else out
@@ -98,3 +102,25 @@ def layernorm(x, gamma, beta, eps=1e-5):
                                   N.ptr(y), N.cur_stream()), "ln")
     torch.cuda.synchronize()
     return y
+
+
+def gemm_tile(cfg):
+    lib = N.load()
+    bm, bn = C.c_int(0), C.c_int(0)
+    lib.sdmi_gemm_config_dims(cfg, C.byref(bm), C.byref(bn))
+    return bm.value, bn.value
+
+
+def ln_fold_prep(w, gamma, beta, bias, n_rows=None):
+    """w: [O][C] cuda fp32/fp16 -> (w_folded fp16 [N][C], g [N], h [N])"""
+    lib = N.load()
+    O, Cc = w.shape
+    n_rows = O if n_rows is None else n_rows
+    wo = torch.empty((n_rows, Cc), dtype=torch.float16, device=w.device)
+    g = torch.empty((n_rows,), dtype=torch.float32, device=w.device)
+    h = torch.empty((n_rows,), dtype=torch.float32, device=w.device)
+    code = N.SDMI_F32 if w.dtype == torch.float32 else N.SDMI_F16
+    N.check(lib.sdmi_op_ln_fold_prep(N.ptr(w.contiguous()), code, N.ptr(gamma), N.ptr(beta), N.ptr(bias), N.ptr(wo), N.ptr(g),
+                                     N.ptr(h), n_rows, Cc, N.cur_stream()), "ln_fold_prep")
+    torch.cuda.synchronize()
+    return wo, g, h

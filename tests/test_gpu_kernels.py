@@ -271,3 +271,71 @@ def test_cfg_ddpm_step_bit_exact_vs_oracle():
                             smp.step_coefficients(t))
             torch.cuda.synchronize()
             assert torch.equal(got.cpu(), want), f"n={n} t={t}: max diff {(got.cpu()-want).abs().max()}"
+
+
+@pytest.mark.parametrize("M,Cc,Nn", [(256, 320, 960), (200, 640, 640), (128, 1280, 5120)])
+def test_layernorm_folded_into_gemm(M, Cc, Nn):
+    """LayerNorm -> Linear as ONE GEMM on the raw tensor (sd/diffusion.py:317-321,334-339,351-356): the producer
+    GEMM's epilogue emits per-row statistics, the consumer applies rstd*(x W'^T - mean*g) + h.  Checked against
+    fp64 LayerNorm + Linear, for every plain tile config on both sides, incl. a stream with a large row mean."""
+    g = torch.Generator().manual_seed(M + Cc + Nn)
+    a = torch.randn((M, Cc), generator=g).half()                              # producer A
+    wp = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()          # producer weights
+    res = (torch.randn((M, Cc), generator=g) * 2 + 3.0)                       # residual with a mean offset (fp32 stream)
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    w = torch.randn((Nn, Cc), generator=g) / math.sqrt(Cc)
+    bias = torch.randn((Nn,), generator=g)
+    x_ref = a.double() @ wp.double().t() + res.double()                       # the stream the LayerNorm sees
+    ref = F.layer_norm(x_ref, (Cc,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + bias.double()
+    wf, gf, hf = G.ln_fold_prep(w.to(DEV), gamma.to(DEV), beta.to(DEV), bias.to(DEV))
+    worst = 0.0
+    cfgs = _plain_cfgs()
+    for i, pc in enumerate(cfgs):
+        bn = G.gemm_tile(pc)[1]
+        ntn = (Cc + bn - 1) // bn
+        rowstat = torch.full((M, ntn, 2), float("nan"), device=DEV)
+        x32, x16 = G.igemm(a.to(DEV).view(1, M, 1, Cc), wp.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, res=res.to(DEV), out_f32=True,
+                           cfg=pc, want16=True, rowstat=rowstat)
+        # emitted statistics = sums of the fp16 shadow, per n-tile
+        x16f = x16.float().cpu()
+        got = rowstat.cpu()
+        for t in range(ntn):
+            blk = x16f[:, t * bn:(t + 1) * bn].double()
+            assert (got[:, t, 0].double() - blk.sum(1)).abs().max().item() < 2e-2
+            assert (got[:, t, 1].double() - (blk * blk).sum(1)).abs().max().item() < 2e-1
+        cc = cfgs[(i * 7 + 3) % len(cfgs)]                                    # consumer tile independent of the producer's
+        out = G.igemm(x16.view(1, M, 1, Cc), wf, B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=hf, out_f32=True, cfg=cc,
+                      ln_stat=rowstat, ln_g=gf, ln_c=Cc)
+        err = (out.cpu().double() - ref).abs().max().item()
+        worst = max(worst, err)
+        assert err < 1.5e-2, f"producer cfg {pc} consumer cfg {cc}: max abs err {err}"
+    # same through the separate LayerNorm kernel + plain GEMM: the folded path must be about as accurate
+    u = G.layernorm(x32, gamma.to(DEV), beta.to(DEV))
+    out2 = G.igemm(u.view(1, M, 1, Cc), w.half().to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias.to(DEV), out_f32=True)
+    err2 = (out2.cpu().double() - ref).abs().max().item()
+    G.log_metric(test="ln_fold", M=M, C=Cc, N=Nn, folded_max_abs=worst, unfused_max_abs=err2)
+    assert worst < 3 * err2 + 2e-3
+
+
+def test_layernorm_fold_transposed_tail():
+    """in_proj with the V^T tail, LayerNorm folded (statistics given per row, one n-tile)."""
+    B, S, Cc = 2, 192, 128
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn((B * S, Cc), generator=g) * 1.5 + 0.7).half()
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    w = torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)
+    ref = F.layer_norm(x.double(), (Cc,), gamma.double(), beta.double(), 1e-5) @ w.double().t()
+    wf, gf, hf = G.ln_fold_prep(w.to(DEV), gamma.to(DEV), beta.to(DEV), None)
+    xs = x.float()
+    stat = torch.stack([xs.sum(1), (xs * xs).sum(1)], 1).view(B * S, 1, 2).contiguous().to(DEV)
+    ldt = 256
+    for cfg in _plain_cfgs():
+        vt = torch.zeros((B * Cc, ldt), dtype=torch.float16, device=DEV)
+        out = G.igemm(x.to(DEV).view(1, B * S, 1, Cc), wf, B=1, Hs=B * S, Ws=1, Ho=B * S, Wo=1, cfg=cfg, bias=hf,
+                      out_t=vt, nt0=2 * Cc, S=S, ldt=ldt, ln_stat=stat, ln_g=gf, ln_c=Cc)
+        assert (out.cpu().double() - ref[:, :2 * Cc]).abs().max().item() < 1.2e-2, f"cfg {cfg}"
+        v_ref = ref[:, 2 * Cc:].view(B, S, Cc).permute(0, 2, 1)
+        got = vt.cpu().double().view(B, Cc, ldt)
+        assert (got[:, :, :S] - v_ref).abs().max().item() < 1.2e-2, f"cfg {cfg} (V^T)"
