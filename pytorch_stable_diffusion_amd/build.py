@@ -20,8 +20,15 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
+FLAGS_STAMP = os.path.join(LIB_DIR, "obj", "flags.txt")
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    # a library built with other SDMI_HIPCC_FLAGS (e.g. the diagnostic -DSDMI_CLK_PROBE build) is stale too
+    extra = os.environ.get("SDMI_HIPCC_FLAGS", "")
+    if not os.path.exists(FLAGS_STAMP) or open(FLAGS_STAMP).read() != extra:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sdmi.h")]
@@ -56,6 +63,8 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(os.environ.get("SDMI_HIPCC_FLAGS", ""))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

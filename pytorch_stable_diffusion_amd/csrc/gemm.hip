@@ -188,6 +188,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 
 #ifdef SDMI_CLK_PROBE
 __device__ unsigned long long g_clk_probe[2048][2];   // diagnostic build only: {shader cycles, 100 MHz ticks} per workgroup
+__device__ unsigned long long g_clk_phase[2048][6];   // {realtime start, end, cycles after setup / K loop / tile in LDS / end}
 #endif
 
 template <class C>
@@ -374,6 +375,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     }
   };
 
+#ifdef SDMI_CLK_PROBE
+  const unsigned long long clk_setup = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   const int nk = kt1 - kt0;
   if constexpr (C::STG == 2) {
     // ---- wave-specialised ring: waves [NW, 2NW) issue LDS-DMA NS-1 intervals ahead, waves [0, NW) run
@@ -493,6 +497,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   }
   }
 
+#ifdef SDMI_CLK_PROBE
+  const unsigned long long clk_loop = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   // ---- epilogue: accumulators -> LDS (fp32, row-major [BM][BN]) -> coalesced global ----------
   float* Cs = (float*)smem;
   if (!producer)
@@ -507,10 +514,17 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
         Cs[row * BN + col] = acc[i][j][e];
       }
   __syncthreads();
+#ifdef SDMI_CLK_PROBE
+  const unsigned long long clk_cs = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
 
   store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid, s_ln, tn, tiles_n);
 #ifdef SDMI_CLK_PROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && blockIdx.x < 2048) {
+    g_clk_phase[blockIdx.x][0] = clk_r0; g_clk_phase[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    g_clk_phase[blockIdx.x][2] = clk_setup; g_clk_phase[blockIdx.x][3] = clk_loop; g_clk_phase[blockIdx.x][4] = clk_cs;
+    g_clk_phase[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - clk_t0;
     g_clk_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk_t0;
     g_clk_probe[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
   }
@@ -518,6 +532,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 }
 
 #ifdef SDMI_CLK_PROBE
+extern "C" int sdmi_dbg_read_phase(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_phase), (size_t)n * 48) == hipSuccess ? 0 : -5;
+}
 extern "C" int sdmi_dbg_read_clk(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_probe), (size_t)n * 16) == hipSuccess ? 0 : -5;
 }
