@@ -46,7 +46,8 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950's register file is unified);
     # removes ~100 v_accvgpr_read/write per attention tile (measured -6% on the S=4096 self-attention)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-             "-mllvm", "-amdgpu-mfma-vgpr-form"]
+             "-mllvm", "-amdgpu-mfma-vgpr-form",
+             "-Rpass-analysis=kernel-resource-usage"]     # per-kernel VGPR / scratch report -> lib/obj/*.resources.txt
     flags += os.environ.get("SDMI_HIPCC_FLAGS", "").split()
     procs = []
     objs = []
@@ -61,8 +62,12 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out, file=sys.stderr)
+        remarks = [l for l in out.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" in l]
+        with open(os.path.join(obj_dir, src.replace(".hip", ".resources.txt")), "w") as f:
+            f.write("\n".join(remarks) + "\n")
+        rest = "\n".join(l for l in out.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" not in l)
+        if verbose and rest.strip():
+            print(rest, file=sys.stderr)
     with open(FLAGS_STAMP, "w") as f:
         f.write(os.environ.get("SDMI_HIPCC_FLAGS", ""))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

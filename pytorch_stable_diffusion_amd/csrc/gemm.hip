@@ -68,15 +68,20 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     // Phase 1 issues EVERY residual / bias load of this thread's items before anything consumes them, so the tile
     // pays one memory latency instead of one per item (a one-K-step workgroup used to live 14 K cycles, most of
     // it in this loop).  Phase 2 reads the tile from LDS, adds, converts and stores.
+    // Items are taken CH at a time so the epilogue's register footprint stays bounded on the big tiles.
     constexpr int ITEMS = (BM * (BN / 8) + NT - 1) / NT;
-    f32x4 r0[ITEMS], r1[ITEMS], b0[ITEMS], b1[ITEMS];
-    f32x4 g0[ITEMS], g1[ITEMS];            // LayerNorm fold: column sums of gamma (.) W
-    f16x8 rh[ITEMS];
+    constexpr int CH = ITEMS < 4 ? ITEMS : (NT >= 1024 ? 2 : 4);    // 1024-thread workgroups: 128 VGPRs per lane
+    static_assert(ITEMS % CH == 0, "epilogue chunking");
     const bool fold = p.ln_stat != nullptr;
-    bool ok[ITEMS];
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = it * NT + tid;
+    for (int ch = 0; ch < ITEMS; ch += CH) {
+    f32x4 r0[CH], r1[CH], b0[CH], b1[CH];
+    f32x4 g0[CH], g1[CH];                  // LayerNorm fold: column sums of gamma (.) W
+    f16x8 rh[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      const int idx = (ch + it) * NT + tid;
       const int row = idx / (BN / 8), c8 = idx % (BN / 8);
       const int m = m0 + row, n = n0 + c8 * 8;
       ok[it] = idx < BM * (BN / 8) && m < p.M && n < p.N;
@@ -99,8 +104,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       }
     }
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = it * NT + tid;
+    for (int it = 0; it < CH; ++it) {
+      const int idx = (ch + it) * NT + tid;
       const int row = idx / (BN / 8), c8 = idx % (BN / 8);
       const int m = m0 + row, n = n0 + c8 * 8;
       float rs = 0.f, rq = 0.f;
@@ -154,6 +159,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         if (c8 == 0 && idx < BM * (BN / 8) && m < p.M) *(f32x2*)(p.rowstat + ((size_t)m * tiles_n + tn) * 2) = f32x2{rs, rq};
       }
     }
+    }   // chunk
   } else {
     // transposed tail: 8 consecutive rows (tokens) of one column -> 16 B along the key axis
     const int Ct = p.N - p.nt0;

@@ -36,3 +36,27 @@ def test_no_oracle_import_in_product():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel must fit its registers: a spill (private-memory scratch) in a GEMM/attention epilogue or
+    main loop is a silent slowdown.  The build stores hipcc's per-kernel resource report next to the objects."""
+    import glob
+    import pytest
+    _native.load()
+    files = glob.glob(os.path.join(ROOT, "pytorch_stable_diffusion_amd", "lib", "obj", "*.resources.txt"))
+    if not files:
+        pytest.skip("prebuilt library without resource reports")
+    n_kernels, bad = 0, []
+    for fn in files:
+        name = None
+        for line in open(fn):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                n_kernels += 1
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) > 0:
+                bad.append((os.path.basename(fn), name, int(m.group(1))))
+    assert n_kernels >= 60, n_kernels
+    assert not bad, f"kernels spilling to scratch: {bad}"
