@@ -35,7 +35,7 @@ struct Cfg {
   static constexpr int RING = NS * KPI * STAGE;
   static constexpr int LDS = (RING > CS_BYTES) ? RING : CS_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  static_assert(NS >= 2 && NS <= 8, "ring depth");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert((BM * 8) % (64 * NW) == 0 && (BN * 8) % (64 * NW) == 0, "staging must divide evenly");
 };
@@ -46,6 +46,20 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   // 16 B per lane, LDS destination = wave-uniform base + lane*16
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Counted wait of an NS-deep LDS-DMA ring: `rem` groups of G loads were issued after the one needed now; up to
+// D = NS-2 of them may stay in flight (the immediate must be a constant, hence the unrolled chain).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int D, int G>
+__device__ __forceinline__ void wait_ring(int rem) {
+  static_assert(D * G <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (D <= 0) wait_vmcnt<0>();
+  else {
+    if (rem >= D) wait_vmcnt<D * G>();
+    else wait_ring<D - 1, G>(rem);
+  }
 }
 
 // Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
@@ -408,10 +422,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       for (int s = 0; s < NS - 1; ++s)
         if (s < ni) stage_interval(s, s);
       {
-        const int rem = ni - 1;
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_ring<NS - 2, G>(ni - 1);
       }
       __builtin_amdgcn_s_barrier();
       int nxt = NS - 1;
@@ -427,9 +438,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
         const int rem = ni - 2 - t;           // intervals issued after interval t+1
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_ring<NS - 2, G>(rem);
 #ifdef SDMI_CLK_PROBE
         const unsigned long long s2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -489,9 +498,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     int cur = 0, nxt = NS - 1;
     for (int t = 0; t < nk; ++t) {
       const int rem = nk - 1 - t;           // groups issued after step t
-      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-      else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_ring<NS - 2, G>(rem);
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < nk) stage(nxt);
       compute(cur);
@@ -911,6 +918,7 @@ const CfgInfo kCfgs[] = {
     // specialised, 8 consumer waves (two MFMA waves per SIMD) + 8 producer waves
     CFG_ENTRY_W2(128, 128, 2, 4, 3, "c8"), CFG_ENTRY_W2(128, 128, 4, 2, 3, "c8m"), CFG_ENTRY_W2(128, 128, 2, 4, 4, "c8"),
     CFG_ENTRY_W2(128, 64, 4, 2, 4, "c8"),  CFG_ENTRY_W2(64, 128, 2, 4, 4, "c8"),
+    // (deeper rings, NS = 6..8, were measured on the weight-streaming M = 128 shapes: no gain over NS = 4)
     // two K-steps per barrier interval
     CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
     CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),

@@ -66,3 +66,8 @@ if __name__ == "__main__":
         bench(2048, 640, 5760, ks=3, H=32, splits=(1, 2, 4, 6))
         bench(512, 1280, 11520, ks=3, H=16, splits=(4, 6, 8, 12))
         bench(128, 1280, 11520, ks=3, H=8, splits=(6, 8, 12, 16))
+    elif which == "stream":      # weight-streaming shapes of the 8x8 level (M = 128)
+        for K in (11520, 23040):
+            bench(128, 1280, K, ks=3, H=8, splits=(4, 6, 8, 12, 16))
+        bench(128, 1280, 5120, splits=(2, 4, 6, 8))
+        bench(512, 1280, 11520, ks=3, H=16, splits=(3, 4, 6, 8))
