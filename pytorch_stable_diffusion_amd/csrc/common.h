@@ -167,4 +167,9 @@ int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* l
 int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st);
 int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, const float* beta, const float* bias,
                             f16* w_out, float* g_out, float* h_out, int N, int C, hipStream_t st);
+int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, f16* out, int N, int K, int J, int ldo,
+                               hipStream_t st);
+int sdmi_launch_compose_bias(const void* A, int a_f32, const float* b_in, const float* b_out, float* out, int N, int K,
+                             hipStream_t st);
+int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int cols, int ld, hipStream_t st);
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);

@@ -45,8 +45,9 @@ struct RowStat { const float* ptr = nullptr; int ntn = 0; };
 
 struct AttnW {
   NormW gn, ln1, ln2, ln3;
-  ConvW conv_in, conv_out, in_proj, out1, q, k, v, out2, g1, g2;
+  ConvW conv_in, in_proj, out1, q, k, v, out2, g1;
   FoldW in_proj_f, q_f, g1_f;      // layernorm_1/2/3 folded into in_proj / q_proj / linear_geglu_1
+  ConvW tail;                      // conv_output o linear_geglu_2 composed: [C][4C | C] over the inputs (geglu | s2)
   int C = 0, dh = 0, ctx_idx = 0;
 };
 struct Act {
@@ -226,6 +227,31 @@ struct Engine {
     res_order.push_back(p);
     return SDMI_OK;
   }
+  // y = conv_output(linear_geglu_2(g) + s2) + x  (sd/diffusion.py:363-381) is linear in (g, s2): composed at load into
+  // ONE GEMM over the virtual concat [g | s2]:  W = [Wo W2 | Wo] (fp32 product, rounded once), b = Wo b2 + bo.
+  // Same FLOPs as the two GEMMs, one launch and one (M, C) fp32 round trip fewer per attention block.
+  int load_tail(const std::string& p, int C, AttnW* a) {
+    const sdmi_tensor_desc *w2, *wo, *b2, *bo;
+    TRY(need(p + ".linear_geglu_2.weight", &w2, 2, {C, 4 * C}));
+    TRY(need(p + ".linear_geglu_2.bias", &b2, 1, {C}));
+    if (find(p + ".conv_output.weight") && find(p + ".conv_output.weight")->ndim == 2) TRY(need(p + ".conv_output.weight", &wo, 2, {C, C}));
+    else TRY(need(p + ".conv_output.weight", &wo, 4, {C, C, 1, 1}));
+    TRY(need(p + ".conv_output.bias", &bo, 1, {C}));
+    ConvW& t = a->tail;
+    t.O = C; t.I = 5 * C; t.ks = 1;
+    TRY(dmalloc(&t.w, (size_t)C * 5 * C * 2));
+    TRY(dmalloc(&t.bias, (size_t)C * 4));
+    float *b2f, *bof;
+    TRY(dmalloc(&b2f, (size_t)C * 4));
+    TRY(dmalloc(&bof, (size_t)C * 4));
+    TRY(sdmi_launch_cast_any_f32(b2->data_dev, b2->dtype == SDMI_F32, b2f, C, st));
+    TRY(sdmi_launch_cast_any_f32(bo->data_dev, bo->dtype == SDMI_F32, bof, C, st));
+    TRY(sdmi_launch_compose_linear(wo->data_dev, wo->dtype == SDMI_F32, w2->data_dev, w2->dtype == SDMI_F32, t.w, C, C, 4 * C, 5 * C, st));
+    TRY(sdmi_launch_cast_rows(wo->data_dev, wo->dtype == SDMI_F32, t.w + 4 * C, C, C, 5 * C, st));
+    TRY(sdmi_launch_compose_bias(wo->data_dev, wo->dtype == SDMI_F32, b2f, bof, t.bias, C, C, st));
+    weight_bytes += (int64_t)C * 5 * C * 2 + (int64_t)C * 4;
+    return SDMI_OK;
+  }
   // first N rows of Linear `p` ([O][C], O >= N) with LayerNorm `ln` folded in
   int load_fold(const std::string& p, int N, int C, const NormW& ln, const float* bias, FoldW* f) {
     const sdmi_tensor_desc* t;
@@ -255,8 +281,7 @@ struct Engine {
     TRY(load_norm(p + ".layernorm_3", C, &a.ln3));
     // quirk Q2 (sd/diffusion.py:359-363): only the first 4C output rows of linear_geglu_1 are live
     TRY(load_conv(p + ".linear_geglu_1", 8 * C, C, 1, true, &a.g1, 4 * C));
-    TRY(load_conv(p + ".linear_geglu_2", C, 4 * C, 1, true, &a.g2));
-    TRY(load_conv(p + ".conv_output", C, C, 1, true, &a.conv_out));
+    TRY(load_tail(p, C, &a));
     TRY(load_fold(p + ".attention_1.in_proj", 3 * C, C, a.ln1, nullptr, &a.in_proj_f));
     TRY(load_fold(p + ".attention_2.q_proj", C, C, a.ln2, nullptr, &a.q_f));
     TRY(load_fold(p + ".linear_geglu_1", 4 * C, C, a.ln3, a.g1.bias, &a.g1_f));
@@ -501,7 +526,7 @@ struct Engine {
     }
     const int B = x.B, S = x.H * x.W, C = w.C, M = x.M();
     const int Spad = ((S + 63) / 64) * 64;
-    Act t0, s0, u, qk, ao, s1, q2, s2, g, s3;
+    Act t0, s0, u, qk, ao, s1, q2, s2, g;
     TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
     TRY(new_act(B, x.H, x.W, C, true, &s0));
     RowStat rs;
@@ -544,10 +569,8 @@ struct Engine {
       a.out = g.h; a.ldc = 4 * C;
       TRY(gemm(a));
     }
-    TRY(new_act(B, x.H, x.W, C, true, &s3));
-    { GemmArgs a = base_args(g, nullptr, w.g2, x.H, x.W, 1, 0); set_res(a, s2); set_out(a, s3); TRY(gemm(a)); }
     TRY(new_act(B, x.H, x.W, C, true, y));
-    { GemmArgs a = base_args(s3, nullptr, w.conv_out, x.H, x.W, 1, 0); set_res(a, x); set_out(a, *y); TRY(gemm(a)); }
+    { GemmArgs a = base_args(g, &s2, w.tail, x.H, x.W, 1, 0); set_res(a, x); set_out(a, *y); TRY(gemm(a)); }
     return SDMI_OK;
   }
 

@@ -351,6 +351,48 @@ __global__ __launch_bounds__(256) void ln_fold_prep_kernel(const void* w_src, in
   }
 }
 
+// Two consecutive linear maps composed at load time (conv_output o linear_geglu_2, sd/diffusion.py:363,381):
+//   out[n][j] = sum_c A[n][c] * B[c][j]   A: [N][K], B: [K][J], fp32 accumulate, fp16 out with row stride ldo.
+__global__ __launch_bounds__(256) void compose_linear_kernel(const void* A, int a_f32, const void* B, int b_f32, f16* out,
+                                                              int N, int K, int J, int ldo) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    float va = 0.f, vb = 0.f;
+    if (n < N && ka < K) va = a_f32 ? ((const float*)A)[(size_t)n * K + ka] : (float)((const f16*)A)[(size_t)n * K + ka];
+    if (kb < K && j < J) vb = b_f32 ? ((const float*)B)[(size_t)kb * J + j] : (float)((const f16*)B)[(size_t)kb * J + j];
+    sa[ty][tx] = va;
+    sb[ty][tx] = vb;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+    __syncthreads();
+  }
+  if (n < N && j < J) out[(size_t)n * ldo + j] = (f16)acc;
+}
+// bias'[n] = sum_c A[n][c] * b_in[c] + b_out[n]
+__global__ __launch_bounds__(64) void compose_bias_kernel(const void* A, int a_f32, const float* b_in, const float* b_out,
+                                                           float* out, int K) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int c = lane; c < K; c += 64)
+    s += (a_f32 ? ((const float*)A)[(size_t)n * K + c] : (float)((const f16*)A)[(size_t)n * K + c]) * b_in[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[n] = s + b_out[n];
+}
+// dst[r][0..cols) (row stride ld) = fp16(src[r][0..cols))
+__global__ __launch_bounds__(256) void cast_rows_kernel(const void* src, int is_f32, f16* dst, int rows, int cols, int ld) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)r * ld + c] = is_f32 ? (f16)((const float*)src)[i] : ((const f16*)src)[i];
+  }
+}
+
 }  // namespace
 
 int sdmi_launch_cast_f32_f16(const float* x, f16* y, size_t n, hipStream_t st) {
@@ -472,6 +514,30 @@ int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, 
                             f16* w_out, float* g_out, float* h_out, int N, int C, hipStream_t st) {
   SDMI_REQUIRE(w_src && gamma && beta && w_out && g_out && h_out && N > 0 && C > 0, "ln_fold_prep: bad arguments");
   hipLaunchKernelGGL(ln_fold_prep_kernel, dim3(N), dim3(256), 0, st, w_src, is_f32, gamma, beta, bias, w_out, g_out, h_out, C);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, f16* out, int N, int K, int J, int ldo,
+                               hipStream_t st) {
+  SDMI_REQUIRE(A && B && out && N > 0 && K > 0 && J > 0 && ldo >= J, "compose_linear: bad arguments");
+  hipLaunchKernelGGL(compose_linear_kernel, dim3((J + 15) / 16, (N + 15) / 16), dim3(256), 0, st, A, a_f32, B, b_f32, out, N, K, J, ldo);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+int sdmi_launch_compose_bias(const void* A, int a_f32, const float* b_in, const float* b_out, float* out, int N, int K,
+                             hipStream_t st) {
+  SDMI_REQUIRE(A && b_in && b_out && out && N > 0 && K > 0, "compose_bias: bad arguments");
+  hipLaunchKernelGGL(compose_bias_kernel, dim3(N), dim3(64), 0, st, A, a_f32, b_in, b_out, out, K);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int cols, int ld, hipStream_t st) {
+  SDMI_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols, "cast_rows: bad arguments");
+  size_t total = (size_t)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_rows_kernel, dim3(blocks), dim3(256), 0, st, src, is_f32, dst, rows, cols, ld);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
