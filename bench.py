@@ -147,11 +147,11 @@ def main():
         # HBM/fabric bytes per step of the same kernel family, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # passes around this command (FETCH_SIZE x2: gfx950 correction), committed under profiles/
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01z_hbm_traffic.json")
         if hw == 64 and os.path.exists(tpath):
             with open(tpath) as tf:
                 traffic = round(json.load(tf)["per_step"]["igemm"]["hbm_bytes"] / 1e9, 3)
-            traffic_src = "profiles/r01_hbm_traffic.json (GB per step, PMC passes of an earlier run of this command)"
+            traffic_src = "profiles/r01z_hbm_traffic.json (GB per step, PMC passes of an earlier run of this command)"
         roof = {
             "bound": "mfma", "kernel": "igemm_kernel + conv3_halo_kernel (all conv3x3/conv1x1/linear launches of a step)",
             "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
@@ -236,7 +236,7 @@ def main():
                        "latency_50_step_loop_ms": round(elapsed / args.steps * 50e3, 1),
                        "image_latency_50_steps_ms": None if image_latency is None else round(image_latency, 1),
                        "vae_decode_ms": None if image_latency is None else round(vae_ms, 2),
-                       "image_latency_note": "pipeline.generate() txt2img 512x512, 50 steps, CFG 7.5: interim torch-ROCm CLIP x2 "
+                       "image_latency_note": "pipeline.generate() txt2img 512x512, 50 steps, CFG 7.5: native HIP CLIP x2 "
                                              "+ native fused loop (CPU noise stream uploaded per step) + native HIP VAE decoder",
                        "baseline_note": "vs_baseline divides by the reference's only published number: 6.06 s/it "
                                         "(0.165 steps/s), CPU fp32, sd/inference_demo.ipynb:91",
