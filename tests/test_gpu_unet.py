@@ -154,3 +154,17 @@ def test_loop_20_steps_vs_reference_generate(full_model):
     mae = (final - ref).abs().mean().item()
     G.log_metric(test="loop20", rel_l2=rel, mae=mae, drift=drift)
     assert rel < 2e-2, f"final latents rel L2 {rel:.2e} (per-step drift {drift})"
+
+
+def test_attention_blocks_with_separate_layernorm_kernel():
+    """The LayerNorm fold is skipped when a producer GEMM is planned split-K; that fallback (layernorm_kernel +
+    plain GEMM) must hold the same parity.  The knob is read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SDMI_NO_LNFOLD="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_unet.py", "-k",
+                        "test_block_vs_golden and attn"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
