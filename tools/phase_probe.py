@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """Diagnostic: life of one workgroup of a small GEMM (build with SDMI_HIPCC_FLAGS=-DSDMI_CLK_PROBE, SDMI_LIB=...).
-usage: phase_probe.py M N K cfgname"""
+usage: [PROBE_KS=3 PROBE_H=16 PROBE_SPLIT=6] phase_probe.py M N K cfgname"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tools.gemm_sweep import bench, names
 lib = C.CDLL(os.environ["SDMI_LIB"])
 M, Nn, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+KS = int(os.environ.get("PROBE_KS", "1")); HH = int(os.environ.get("PROBE_H", "1")); SP = int(os.environ.get("PROBE_SPLIT", "1"))
 for cfgname in sys.argv[4:]:
     cfg = names.index(cfgname)
     for _ in range(2):
-        r = bench(M, Nn, K, ks=1, H=1, cfgs=[cfg], splits=(1,), iters=100)
+        r = bench(M, Nn, K, ks=KS, H=HH, cfgs=[cfg], splits=(SP,), iters=100)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (6 * 2048))()
     lib.sdmi_dbg_read_phase(buf, 2048)
