@@ -37,6 +37,7 @@ struct ACfg {
   static constexpr int V_BYTES = DP * 128;
   static constexpr int V_INST = DP / 8;
   static constexpr int STAGE = K_BYTES + V_BYTES;
+  static constexpr bool LROW = DP > D;             // a spare V^T row exists (d = 40, 80): row sums come from the MFMA
   static constexpr int LDS = 2 * STAGE;
 };
 
@@ -72,7 +73,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const int q = (i * 4 + wave) * 64 + lane;
     const int row = q >> 3, pc = q & 7;
     const int gch = pc ^ ((row >> 1) & 7);
-    vptr[i] = row < D ? vbase + (size_t)row * p.ldvt + gch * 8 : p.zero + gch * 8;
+    // row D of the padded V^T tile is all ones: the PV MFMA then also produces the row sums of P (the softmax
+    // denominator) in accumulator row D, and the VALU never adds the probabilities up
+    vptr[i] = row < D ? vbase + (size_t)row * p.ldvt + gch * 8 : ((C::LROW && row == D) ? p.ones : p.zero) + gch * 8;
     vinc[i] = row < D ? 64 : 0;
   }
   const size_t kstep = (size_t)64 * p.ldk;
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       const int dk = 16 * s + 8 * h;
       if (dk < D) {
         qf[s] = *(const f16x8*)(qp + dk);
+        if (!p.prescaled) {          // op-level callers hand over plain q: scale here (one extra fp16 rounding)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[s][e] = (f16)((float)qf[s][e] * (p.scale * 1.4426950408889634f));
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[s][e] = (f16)0.f;
@@ -130,12 +137,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   for (int d = 0; d < C::DB; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = p.scale * 1.4426950408889634f;
+  // Scores arrive in the log2 domain (Q carries scale*log2 e).  The running max m_run is subtracted INSIDE the QK^T
+  // chain by one extra k16 step: K side = 1 at k-index 0, Q side = -m_run (kept exactly representable in fp16), so the
+  // softmax is p = exp2(acc) with no per-score multiply or subtract on the VALU.
+  float m_run = 0.f, l_run = 0.f;
+  f16x8 kbias, qbias;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { kbias[e] = (f16)0.f; qbias[e] = (f16)0.f; }
+  if (h == 0) kbias[0] = (f16)1.f;
 
-  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T
-  auto tile_body = [&](auto masked_tag, int t, int cur) {
+  // one 64-key tile: S'^T = K Q'^T - m_run, online softmax, O^T += V^T P^T.  FIRST: tile 0 (m_run not set yet).
+  auto tile_body = [&](auto masked_tag, auto first_tag, int t, int cur) {
     constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
     const char* Ks = smem + cur * C::STAGE;
     const char* Vs = Ks + C::K_BYTES;
     f32x16 sacc[2];
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r) * (D * 2) + koff[s]);
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
+      if constexpr (!FIRST) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kbias, qbias, sacc[kb], 0, 0, 0);
     }
     if constexpr (MASKED) {   // keys beyond Skv (ragged last tile) and, for causal attention, keys after the query
       const int kbase_i = t * 64 + 4 * h;
@@ -160,9 +175,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
           if (key >= p.Skv || key > qlim) sacc[kb][e] = -INFINITY;
         }
     }
-    // online softmax (per query = per lane; the two half-waves hold disjoint keys).  Lazy rescale:
-    // the running max is raised (and O, l rescaled) only when some query's tile max exceeds it by
-    // more than 2^8 in the exp2 domain; otherwise P <= 256 (fine for fp16 P, fp32 l/O).  Wave-uniform.
+    // online softmax (per query = per lane; the two half-waves hold disjoint keys).  Lazy rescale: the running max is
+    // raised (and O, l rescaled) only when some query's tile max exceeds it by more than 2^8; otherwise P <= 256
+    // (fine for fp16 P, fp32 l/O).  Wave-uniform branch.
     float mx0 = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
     float mx1 = fmaxf(fmaxf(sacc[1][0], sacc[1][1]), sacc[1][2]);
 #pragma unroll
@@ -172,28 +187,36 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
     float mx = fmaxf(fmaxf(mx0, sacc[0][15]), fmaxf(mx1, sacc[1][15]));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (__any((mx - m_run) * c > 8.f)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
+    if (FIRST || __any(mx > 8.f)) {
+      float d = FIRST ? mx : fmaxf(mx, 0.f);
+      if (!(d > -60000.f)) d = 0.f;                       // a query with no valid key in this tile keeps its max
+      const float m_new = (float)(f16)(m_run + d);          // exactly representable: it re-enters through qbias
+      const float de = m_new - m_run;
+      if constexpr (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(-de);
+        l_run *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < C::DB; ++dd)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[dd][e] *= alpha;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kb][e] -= de;
       m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      qbias[0] = h == 0 ? (f16)(-m_run) : (f16)0.f;
     }
-    const float mc = m_run * c;
     float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float p0 = __builtin_amdgcn_exp2f(sacc[0][e] * c - mc);
-      const float p1 = __builtin_amdgcn_exp2f(sacc[1][e] * c - mc);
+      const float p0 = __builtin_amdgcn_exp2f(sacc[0][e]);
+      const float p1 = __builtin_amdgcn_exp2f(sacc[1][e]);
       sacc[0][e] = p0;
       sacc[1][e] = p1;
-      ps0 += p0;
-      ps1 += p1;
+      if constexpr (!C::LROW) { ps0 += p0; ps1 += p1; }
     }
-    l_run += ps0 + ps1;
+    if constexpr (!C::LROW) l_run += ps0 + ps1;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -225,8 +248,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) stage(cur ^ 1);
-    if (t < nfull) tile_body(std::false_type{}, t, cur);
-    else tile_body(std::true_type{}, t, cur);
+    if (t == 0) {
+      if (nfull > 0) tile_body(std::false_type{}, std::true_type{}, t, cur);
+      else tile_body(std::true_type{}, std::true_type{}, t, cur);
+    } else if (t < nfull) tile_body(std::false_type{}, std::false_type{}, t, cur);
+    else tile_body(std::true_type{}, std::false_type{}, t, cur);
     if (t + 1 < ntiles) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -235,7 +261,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 
   // ---- normalise and store: lane = query row, registers = head-dim ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if constexpr (C::LROW) l_tot = __shfl(oacc[D / 32][4 * ((D % 32) / 8)], r);   // accumulator row D (lane r of the low half)
+  else l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.f / l_tot;
   const int qi = q0 + r;
   if (qi < p.Sq) {
@@ -272,7 +300,7 @@ int launch(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 int sdmi_launch_attention(const AttnArgs& a, hipStream_t st) {
-  SDMI_REQUIRE(a.q && a.k && a.vt && a.o && a.zero, "attention: null pointer");
+  SDMI_REQUIRE(a.q && a.k && a.vt && a.o && a.zero && a.ones, "attention: null pointer");
   SDMI_REQUIRE(a.Sq > 0 && a.Skv > 0 && a.B > 0 && a.H > 0, "attention: bad sizes");
   SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "attention: strides must be 16-B aligned");
   SDMI_REQUIRE(a.ldvt >= ((a.Skv + 63) / 64) * 64, "attention: V^T rows must be padded to a multiple of 64 keys (ldvt=%d, Skv=%d)", a.ldvt, a.Skv);

@@ -35,6 +35,7 @@ int sdmi_clip_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   int rc;
   if ((rc = c->dmalloc(&c->zero, 4096)) != SDMI_OK) return fail(rc);
   if (hipMemset(c->zero, 0, 4096) != hipSuccess) return fail(SDMI_EHIP);
+  if (hipMemsetD16((hipDeviceptr_t)(c->zero + 1024), 0x3C00, 1024) != hipSuccess) return fail(SDMI_EHIP);   // fp16 ones
   {
     const sdmi_tensor_desc* t;
     if ((rc = c->need("embedding.token_embedding.weight", &t, 2, {kVocab, kDim})) != SDMI_OK) return fail(rc);
@@ -93,6 +94,7 @@ int sdmi_clip_encode(sdmi_clip* c, const int64_t* tokens_dev, float* out_dev, in
       GemmArgs a = Engine::base_args(u, nullptr, w.in_proj, kTok, 1, 1, 0);
       a.out = qk.h; a.ldc = 2 * kDim;
       a.outT = vt; a.nt0 = 2 * kDim; a.S = kTok; a.ldt = kVtLd;
+      a.cscale = 1.4426950408889634f / sqrtf((float)kDh); a.cs_hi = kDim;     // Q columns carry scale * log2(e)
       TRY(c->gemm(a));
     }
     TRY(c->new_act(batch, kTok, 1, kDim, false, &ao));
@@ -101,7 +103,7 @@ int sdmi_clip_encode(sdmi_clip* c, const int64_t* tokens_dev, float* out_dev, in
       memset(&t, 0, sizeof(t));
       t.q = qk.h; t.ldq = 2 * kDim; t.k = qk.h + kDim; t.ldk = 2 * kDim; t.k_batch_stride = kTok;
       t.vt = vt; t.ldvt = kVtLd; t.o = ao.h; t.ldo = kDim; t.B = batch; t.H = kClipHeads; t.d = kDh;
-      t.Sq = kTok; t.Skv = kTok; t.zero = c->zero; t.scale = 1.f / sqrtf((float)kDh); t.causal = 1;
+      t.Sq = kTok; t.Skv = kTok; t.zero = c->zero; t.ones = c->zero + 1024; t.scale = 1.f / sqrtf((float)kDh); t.prescaled = 1; t.causal = 1;
       TRY(sdmi_launch_attention(t, c->st));
       c->launches += 1;
     }

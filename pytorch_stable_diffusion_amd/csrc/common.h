@@ -85,6 +85,9 @@ struct GemmArgs {
   //    over this n-tile to rowstat[(m*tiles_n + tn)*2] (ksplit == 1, no transposed tail);
   //  consumer side: ln_stat != null -> A is the RAW stream, w = gamma (.) W, and the epilogue applies
   //    out = rstd[m]*(acc - mean[m]*ln_g[n]) + bias[n], mean/rstd from ln_stat[m][0..ln_ntn) over ln_C columns.
+  // columns n < cs_hi are multiplied by cscale after bias (the attention kernel takes Q pre-multiplied by
+  // log2(e)/sqrt(d): folded into the projection in fp32, before the fp16 rounding); cs_hi = 0: off, multiple of 8
+  float cscale; int cs_hi;
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_C; float ln_eps;
 };
@@ -107,7 +110,9 @@ struct AttnArgs {
   int Sq, Skv;               // Skv = number of valid keys (masking beyond)
   int k_batch_stride;        // rows of k per batch (>= Skv)
   const f16* zero;
+  const f16* ones;           // >= 256 B of fp16 1.0 (source of the row-sum row of the V^T tile)
   float scale;               // 1/sqrt(d)
+  int prescaled;             // 1: q already carries scale*log2(e) (folded into its projection); 0: the kernel scales Q
   int causal;                // 1: key index > query index is masked (CLIP, sd/attention.py:58-62)
 };
 int sdmi_launch_attention(const AttnArgs& a, hipStream_t st);

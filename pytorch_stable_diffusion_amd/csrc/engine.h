@@ -501,8 +501,8 @@ struct Engine {
     AttnArgs t;
     memset(&t, 0, sizeof(t));
     t.q = q; t.ldq = ldq; t.k = k; t.ldk = ldk; t.k_batch_stride = kbs; t.vt = vt; t.ldvt = ldvt;
-    t.o = o; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero;
-    t.scale = 1.f / sqrtf((float)d);
+    t.o = o; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero; t.ones = zero + 1024;
+    t.scale = 1.f / sqrtf((float)d); t.prescaled = 1;       // callers fold scale*log2(e) into the Q projection (q_scale)
     prof_begin(1, 4.0 * B * kHeads * (double)Sq * Skv * d);
     TRY(sdmi_launch_attention(t, st));
     prof_end();
@@ -516,6 +516,9 @@ struct Engine {
     a.w = f.w; a.bias = f.h;
     a.ln_stat = rs.ptr; a.ln_ntn = rs.ntn; a.ln_g = f.g; a.ln_C = C; a.ln_eps = 1e-5f;
   }
+
+  // factor folded into every Q projection feeding `attention()`: softmax(q k^T / sqrt(d)) = 2^(q' k^T) normalised
+  static float q_scale(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 
   // UNET_AttentionBlock (sd/diffusion.py:271-381)
   int attn_block(const AttnW& w, const Act& x, Act* y) {
@@ -542,6 +545,7 @@ struct Engine {
       if (rs.ptr) fold_ln(a, w.in_proj_f, rs, C);
       a.out = qk.h; a.ldc = 2 * C;
       a.outT = vt; a.nt0 = 2 * C; a.S = S; a.ldt = Spad;
+      a.cscale = q_scale(w.dh); a.cs_hi = C;
       TRY(gemm(a));
     }
     TRY(new_act(B, x.H, x.W, C, false, &ao));
@@ -555,6 +559,7 @@ struct Engine {
       GemmArgs a = base_args(rs.ptr ? s1 : u, nullptr, w.q, x.H, x.W, 1, 0);
       if (rs.ptr) fold_ln(a, w.q_f, rs, C);
       a.out = q2.h; a.ldc = C;
+      a.cscale = q_scale(w.dh); a.cs_hi = C;
       TRY(gemm(a));
     }
     TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));

@@ -141,6 +141,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
             v[4 + e] = v1[e] + b1[it][e];
           }
         }
+        if (n < p.cs_hi) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.cscale;
+        }
         if (p.act == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
@@ -844,6 +848,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
     }
+    if (n < p.cs_hi) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.cscale;
+    }
     if (p.act == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
@@ -991,6 +999,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.M > 0, "gemm: M=%d", a.M);
   SDMI_REQUIRE(a.C0 % 64 == 0 && a.C1 % 64 == 0 && a.C0 > 0, "gemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
   SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1) + a.X0 + a.X1, "gemm: K=%d != ks^2*(C0+C1) + X0+X1", a.K);
+  SDMI_REQUIRE(a.cs_hi % 8 == 0 && (a.cs_hi == 0 || !a.outT || a.cs_hi <= a.nt0), "gemm: scaled column range must be a multiple of 8 outside the transposed tail");
   SDMI_REQUIRE(!a.rowstat || (a.ksplit <= 1 && !a.outT), "gemm: row statistics need ksplit == 1 and no transposed tail");
   SDMI_REQUIRE(!a.ln_stat || (a.ksplit <= 1 && a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && !a.res), "gemm: bad LayerNorm-fold arguments");
   SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");

@@ -191,6 +191,7 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   int rc;
   if ((rc = u->dmalloc(&u->zero, 4096)) != SDMI_OK) return fail(rc);
   if (hipMemset(u->zero, 0, 4096) != hipSuccess) return fail(SDMI_EHIP);
+  if (hipMemsetD16((hipDeviceptr_t)(u->zero + 1024), 0x3C00, 1024) != hipSuccess) return fail(SDMI_EHIP);   // fp16 ones (Engine::ones)
   const bool len = u->partial;
   // time embedding
   if (!len || u->has("time_embedding.linear_1.weight")) {
@@ -410,6 +411,7 @@ static int ensure_globals(size_t slab_need) {
   if (!g_zero) {
     SDMI_CHECK_HIP(hipMalloc((void**)&g_zero, 4096));
     SDMI_CHECK_HIP(hipMemset(g_zero, 0, 4096));
+    SDMI_CHECK_HIP(hipMemsetD16((hipDeviceptr_t)(g_zero + 1024), 0x3C00, 1024));   // second half: fp16 ones
   }
   if (slab_need > g_slab_bytes) {
     if (g_slab) (void)hipFree(g_slab);
@@ -475,7 +477,7 @@ int sdmi_op_attention(const void* q, int ldq, const void* k, int ldk, int k_batc
   memset(&t, 0, sizeof(t));
   t.q = (const f16*)q; t.ldq = ldq; t.k = (const f16*)k; t.ldk = ldk; t.k_batch_stride = k_batch_stride;
   t.vt = (const f16*)vt; t.ldvt = ldvt; t.o = (f16*)o; t.ldo = ldo; t.B = B; t.H = H; t.d = d; t.Sq = Sq; t.Skv = Skv;
-  t.zero = g_zero; t.scale = 1.f / sqrtf((float)d);
+  t.zero = g_zero; t.ones = g_zero + 1024; t.scale = 1.f / sqrtf((float)d); t.prescaled = 0;
   return sdmi_launch_attention(t, (hipStream_t)stream);
 }
 
