@@ -132,7 +132,8 @@ int sdmi_clip_last_launch_count(const sdmi_clip* c);
 /* Implicit-GEMM conv / linear:  out[m][n] = sum_k A(m,k) w[n][k] + bias[n] + res[m][n].
  * a0/a1: NHWC fp16 sources (virtual channel concat), w: packed [N][ks*ks*(c0+c1)] fp16 with k ordered
  * (kh,kw,ci).  cfg < 0: heuristic tile; ksplit >= 1.  out_t (optional): columns >= nt0 written
- * transposed as out_t[(b*(N-nt0)+n-nt0)*ldt + s] with m = b*S + s. */
+ * transposed as out_t[(b*(N-nt0)+n-nt0)*ldt + pos(s)] with m = b*S + s; pos(s) = s, or with out_t_perm the four 4-key
+ * quads of every 16-key group in the order (q0, q2, q1, q3) -- the V^T layout sdmi_op_attention reads (ldt % 16 == 0). */
 typedef struct sdmi_gemm_desc {
   const void* a0; const void* a1;
   int c0, c1, hs, ws, ho, wo, ups, stride, pad, ks;
@@ -154,6 +155,7 @@ typedef struct sdmi_gemm_desc {
    * out = rstd[m]*(acc - mean[m]*ln_g[n]) + bias[n], statistics summed from ln_stat[m][0..ln_ntn) over ln_c columns. */
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_c; float ln_eps;
+  int out_t_perm;   /* 1: out_t's key axis in the quad-permuted order sdmi_op_attention reads; 0: natural order */
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
@@ -171,8 +173,9 @@ int sdmi_op_ln_fold_prep(const void* w_dev, int w_dtype, const float* gamma, con
 /* PyTorch OIHW (fp32/fp16) -> packed [o < o_keep][kh][kw][I] fp16. */
 int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream);
 
-/* Flash attention: q [B*Sq][ldq], k [B*k_batch_stride][ldk], vt [(b*H+h)*d+dd][ldvt] (keys
- * contiguous, zero-padded to a multiple of 64), o [B*Sq][ldo]; all fp16. */
+/* Flash attention: q [B*Sq][ldq], k [B*k_batch_stride][ldk], vt [(b*H+h)*d+dd][ldvt] (keys along the row in the
+ * quad-permuted order sdmi_op_gemm's out_t writes, zero-padded to a multiple of 64), o [B*Sq][ldo]; all fp16.
+ * q is plain: the kernel applies 1/sqrt(d) itself on this entry point. */
 int sdmi_op_attention(const void* q, int ldq, const void* k, int ldk, int k_batch_stride, const void* vt, int ldvt,
                       void* o, int ldo, int B, int H, int d, int Sq, int Skv, void* stream);
 

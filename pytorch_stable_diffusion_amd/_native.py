@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
                 ("cfg", C.c_int), ("ksplit", C.c_int),
                 ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int),
                 ("rowstat", C.c_void_p), ("ln_stat", C.c_void_p), ("ln_ntn", C.c_int), ("ln_g", C.c_void_p),
-                ("ln_c", C.c_int), ("ln_eps", C.c_float)]
+                ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
     float mx = fmaxf(fmaxf(mx0, sacc[0][15]), fmaxf(mx1, sacc[1][15]));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (FIRST || __any(mx > 8.f)) {
+    if (FIRST || __builtin_expect(__any(mx > 8.f), 0)) {
       float d = FIRST ? mx : fmaxf(mx, 0.f);
       if (!(d > -60000.f)) d = 0.f;                       // a query with no valid key in this tile keeps its max
       const float m_new = (float)(f16)(m_run + d);          // exactly representable: it re-enters through qbias
@@ -224,17 +224,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         f16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[e] = (f16)sacc[kb][8 * s2 + e];
-        const int ch0 = 4 * kb + 2 * s2;
-        const int o0 = ((ch0 ^ vkey) << 4) + 8 * h;
-        const int o1 = (((ch0 + 1) ^ vkey) << 4) + 8 * h;
+        // keys of this k16 step held by half h: quads h and 2+h of 16-key group 2*kb + s2 -- adjacent in the
+        // permuted V^T storage (gemm.hip vt_pos): one 16-byte read at chunk 2*group + h
+        const int o0 = (((4 * kb + 2 * s2 + h) ^ vkey) << 4);
 #pragma unroll
         for (int d = 0; d < C::DB; ++d) {
-          const char* vrow = Vs + (d * 32 + r) * 128;
-          const f16x4 lo = *(const f16x4*)(vrow + o0);
-          const f16x4 hi = *(const f16x4*)(vrow + o1);
-          f16x8 vf;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+          const f16x8 vf = *(const f16x8*)(Vs + (d * 32 + r) * 128 + o0);
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
         }
       }
@@ -245,20 +240,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   __syncthreads();
   const bool ragged = (p.Skv & 63) != 0;
   const int nfull = p.causal ? 0 : (ragged ? ntiles - 1 : ntiles);   // tiles that need no masking
+  // Three runs of tiles, each with ONE body in its loop (separate loops keep the accumulators in place: with both
+  // bodies in one loop the register allocator copied all of O^T every tile): tile 0, unmasked tiles, masked tail.
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
+  auto step = [&](int t, auto masked_tag, auto first_tag) {
     if (t + 1 < ntiles) stage(cur ^ 1);
-    if (t == 0) {
-      if (nfull > 0) tile_body(std::false_type{}, std::true_type{}, t, cur);
-      else tile_body(std::true_type{}, std::true_type{}, t, cur);
-    } else if (t < nfull) tile_body(std::false_type{}, std::false_type{}, t, cur);
-    else tile_body(std::true_type{}, std::false_type{}, t, cur);
+    tile_body(masked_tag, first_tag, t, cur);
     if (t + 1 < ntiles) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     cur ^= 1;
-  }
+  };
+  if (nfull > 0) step(0, std::false_type{}, std::true_type{});
+  else step(0, std::true_type{}, std::true_type{});
+  int t = 1;
+  for (; t < nfull; ++t) step(t, std::false_type{}, std::false_type{});
+  for (; t < ntiles; ++t) step(t, std::true_type{}, std::false_type{});
 
   // ---- normalise and store: lane = query row, registers = head-dim ----
   float l_tot;

@@ -93,7 +93,7 @@ int sdmi_clip_encode(sdmi_clip* c, const int64_t* tokens_dev, float* out_dev, in
     {
       GemmArgs a = Engine::base_args(u, nullptr, w.in_proj, kTok, 1, 1, 0);
       a.out = qk.h; a.ldc = 2 * kDim;
-      a.outT = vt; a.nt0 = 2 * kDim; a.S = kTok; a.ldt = kVtLd;
+      a.outT = vt; a.nt0 = 2 * kDim; a.S = kTok; a.ldt = kVtLd; a.tperm = 1;
       a.cscale = 1.4426950408889634f / sqrtf((float)kDh); a.cs_hi = kDim;     // Q columns carry scale * log2(e)
       TRY(c->gemm(a));
     }

@@ -75,6 +75,7 @@ struct GemmArgs {
   int nt0;
   int S;
   int ldt;
+  int tperm;           // 1: store the key axis of outT in the attention kernel's quad-permuted order (gemm.hip vt_pos)
   // split-K: partial sums to slab[z][M][N] (fp32), combined by splitk_finalize
   float* slab;
   int ksplit;

@@ -544,7 +544,7 @@ struct Engine {
       GemmArgs a = base_args(rs.ptr ? s0 : u, nullptr, w.in_proj, x.H, x.W, 1, 0);
       if (rs.ptr) fold_ln(a, w.in_proj_f, rs, C);
       a.out = qk.h; a.ldc = 2 * C;
-      a.outT = vt; a.nt0 = 2 * C; a.S = S; a.ldt = Spad;
+      a.outT = vt; a.nt0 = 2 * C; a.S = S; a.ldt = Spad; a.tperm = 1;
       a.cscale = q_scale(w.dh); a.cs_hi = C;
       TRY(gemm(a));
     }

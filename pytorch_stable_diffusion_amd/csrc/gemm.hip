@@ -62,6 +62,16 @@ __device__ __forceinline__ void wait_ring(int rem) {
   }
 }
 
+// Position of key s inside a V^T row.  Within every group of 16 keys the four 4-key quads are stored in the order
+// (q0, q2, q1, q3): the PV MFMA of the attention kernel wants, per lane half h, the quads h and 2+h of a group as ONE
+// 16-byte LDS read (quads 0,2 | 1,3 become adjacent).  Purely a storage permutation of the key axis.
+__device__ __forceinline__ int vt_pos(int s, int perm) {
+  if (!perm) return s;
+  const int u = s >> 2, g = u & 3;
+  const int gp = (g == 1) ? 2 : (g == 2) ? 1 : g;
+  return (((u & ~3) | gp) << 2) | (s & 3);
+}
+
 // Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
 // V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
 template <int BM, int BN, int NT>
@@ -195,14 +205,16 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       }
       if ((p.S & 7) == 0) {
         const int b = m / p.S, s = m - b * p.S;
-        *(f16x8*)(p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt + s) = o16;
+        f16* row = p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt;
+        *(f16x4*)(row + vt_pos(s, p.tperm)) = f16x4{o16[0], o16[1], o16[2], o16[3]};
+        *(f16x4*)(row + vt_pos(s + 4, p.tperm)) = f16x4{o16[4], o16[5], o16[6], o16[7]};
       } else {   // tiny maps (S not a multiple of 8): element-wise, rows may straddle images
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int me = m + e;
           if (me < p.M) {
             const int b = me / p.S, s = me - b * p.S;
-            p.outT[((size_t)b * Ct + (n - p.nt0)) * p.ldt + s] = o16[e];
+            p.outT[((size_t)b * Ct + (n - p.nt0)) * p.ldt + vt_pos(s, p.tperm)] = o16[e];
           }
         }
       }
@@ -861,7 +873,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
       const int Ct = p.N - p.nt0;
       const int b = m / p.S, s = m - b * p.S;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) p.outT[((size_t)b * Ct + (n + e - p.nt0)) * p.ldt + s] = (f16)v[e];
+      for (int e = 0; e < 8; ++e) p.outT[((size_t)b * Ct + (n + e - p.nt0)) * p.ldt + vt_pos(s, p.tperm)] = (f16)v[e];
       continue;
     }
     if (p.res) {
@@ -1013,7 +1025,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
-    SDMI_REQUIRE(a.S > 0 && a.ldt % 8 == 0, "gemm: transposed tail needs S > 0 and ldt a multiple of 8");
+    SDMI_REQUIRE(a.S > 0 && a.ldt % (a.tperm ? 16 : 8) == 0, "gemm: transposed tail needs S > 0 and ldt a multiple of 8 (16 with the quad-permuted key order)");
   }
   const int nkt = a.K / 64;
   GemmArgs p = a;

@@ -264,7 +264,7 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
       GemmArgs a = Engine::base_args(c, nullptr, w.v, kCtxPad, 1, 1, 0);
       a.out = u->ctxK[i];   // unused (all columns go to the transposed tail)
       a.ldc = w.C;
-      a.outT = u->ctxVt[i]; a.nt0 = 0; a.S = kCtxPad; a.ldt = kCtxVtLd;
+      a.outT = u->ctxVt[i]; a.nt0 = 0; a.S = kCtxPad; a.ldt = kCtxVtLd; a.tperm = 1;
       TRY(u->gemm(a));
     }
   }
@@ -430,7 +430,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.M = d->M; a.N = d->N; a.K = d->K; a.w = (const f16*)d->w; a.bias = d->bias;
   a.res = d->res; a.res_f32 = d->res_f32; a.ldr = d->ldr;
   a.out = d->out; a.out_f32 = d->out_f32; a.ldc = d->ldc; a.out16 = (f16*)d->out16;
-  a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt;
+  a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt; a.tperm = d->out_t_perm;
   a.x0 = (const f16*)d->x0; a.x1 = (const f16*)d->x1; a.X0 = d->cx0; a.X1 = d->cx1;
   a.rowstat = d->rowstat; a.ln_stat = d->ln_stat; a.ln_ntn = d->ln_ntn; a.ln_g = d->ln_g; a.ln_C = d->ln_c; a.ln_eps = d->ln_eps;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;

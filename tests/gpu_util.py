@@ -37,7 +37,7 @@ def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
 
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
-          rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5):
+          rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
@@ -62,6 +62,7 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.out16 = 0 if out16 is None else out16.data_ptr()
     d.out_t = 0 if out_t is None else out_t.data_ptr()
     d.nt0, d.S, d.ldt = nt0, S, ldt
+    d.out_t_perm = out_t_perm
     d.cfg, d.ksplit = cfg, ksplit
     d.x0 = 0 if x0 is None else x0.data_ptr(); d.cx0 = 0 if x0 is None else x0.shape[-1]
     d.x1 = 0 if x1 is None else x1.data_ptr(); d.cx1 = 0 if x1 is None else x1.shape[-1]
@@ -73,8 +74,33 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     return (out, out16) if want16 else out
 
 
+def _vt_index(n):
+    """stored position -> key index along a V^T row: inside each group of 16 keys the 4-key quads are stored
+    in the order (q0, q2, q1, q3)  (csrc/gemm.hip vt_pos; the PV MFMA reads quads h and 2+h as one 16-byte load)."""
+    idx = torch.arange(n)
+    u, g = idx // 4, (idx // 4) % 4
+    gp = torch.where(g == 1, torch.full_like(g, 2), torch.where(g == 2, torch.full_like(g, 1), g))
+    pos = ((u - g + gp) * 4) + idx % 4          # pos[key] = stored position
+    inv = torch.empty_like(pos)
+    inv[pos] = idx
+    return pos, inv
+
+
+def vt_store_order(vt_natural):
+    """(rows, keys) with keys in natural order -> the library's stored order (keys padded to a multiple of 16)"""
+    _, inv = _vt_index(vt_natural.shape[-1])
+    return vt_natural[..., inv.to(vt_natural.device)].contiguous()
+
+
+def vt_natural_order(vt_stored):
+    pos, _ = _vt_index(vt_stored.shape[-1])
+    return vt_stored[..., pos.to(vt_stored.device)].contiguous()
+
+
 def attention(q, k, vt, B, H, d, Sq, Skv, k_batch_stride=None):
+    """vt: V^T with keys in NATURAL order (rows padded to a multiple of 64 keys); permuted here for the library."""
     lib = N.load()
+    vt = vt_store_order(vt)
     o = torch.zeros((B * Sq, H * d), dtype=torch.float16, device=q.device)
     kbs = Skv if k_batch_stride is None else k_batch_stride
     N.check(lib.sdmi_op_attention(N.ptr(q), q.shape[-1], N.ptr(k), k.shape[-1], kbs, N.ptr(vt), vt.shape[-1],

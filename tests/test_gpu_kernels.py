@@ -154,12 +154,13 @@ def test_gemm_transposed_tail():
     ldt = 256
     for cfg in _plain_cfgs():
         for ksplit in (1, 2):
+            perm = (cfg + ksplit) & 1          # natural order (VAE) and the attention kernel's quad-permuted order
             vt = torch.zeros((B * Cc, ldt), dtype=torch.float16, device=DEV)
             out = G.igemm(a.to(DEV).view(1, B * S, 1, Cc), w.to(DEV), B=1, Hs=B * S, Ws=1, Ho=B * S, Wo=1, cfg=cfg,
-                          ksplit=ksplit, out_t=vt, nt0=2 * Cc, S=S, ldt=ldt)
+                          ksplit=ksplit, out_t=vt, nt0=2 * Cc, S=S, ldt=ldt, out_t_perm=perm)
             assert (out.cpu().double() - ref[:, :2 * Cc]).abs().max().item() < 8e-3
             v_ref = ref[:, 2 * Cc:].view(B, S, Cc).permute(0, 2, 1)        # (B, C, S)
-            got = vt.cpu().double().view(B, Cc, ldt)
+            got = (G.vt_natural_order(vt.cpu()) if perm else vt.cpu()).double().view(B, Cc, ldt)
             assert (got[:, :, :S] - v_ref).abs().max().item() < 8e-3, f"cfg {cfg} ksplit {ksplit}"
             assert got[:, :, S:].abs().max().item() == 0.0
 
@@ -334,8 +335,8 @@ def test_layernorm_fold_transposed_tail():
     for cfg in _plain_cfgs():
         vt = torch.zeros((B * Cc, ldt), dtype=torch.float16, device=DEV)
         out = G.igemm(x.to(DEV).view(1, B * S, 1, Cc), wf, B=1, Hs=B * S, Ws=1, Ho=B * S, Wo=1, cfg=cfg, bias=hf,
-                      out_t=vt, nt0=2 * Cc, S=S, ldt=ldt, ln_stat=stat, ln_g=gf, ln_c=Cc)
+                      out_t=vt, nt0=2 * Cc, S=S, ldt=ldt, ln_stat=stat, ln_g=gf, ln_c=Cc, out_t_perm=1)
         assert (out.cpu().double() - ref[:, :2 * Cc]).abs().max().item() < 1.2e-2, f"cfg {cfg}"
         v_ref = ref[:, 2 * Cc:].view(B, S, Cc).permute(0, 2, 1)
-        got = vt.cpu().double().view(B, Cc, ldt)
+        got = G.vt_natural_order(vt.cpu()).double().view(B, Cc, ldt)
         assert (got[:, :, :S] - v_ref).abs().max().item() < 1.2e-2, f"cfg {cfg} (V^T)"
