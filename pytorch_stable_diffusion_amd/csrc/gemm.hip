@@ -850,11 +850,38 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    for (int z = 0; z < p.ksplit; ++z) {
-      const float* sp = p.slab + (size_t)z * MN + (size_t)m * p.N + n;
-      const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+    const bool transposed = p.outT != nullptr && n >= p.nt0;
+    // residual issued first: it is the coldest load of the item
+    f32x4 rf0 = {0.f, 0.f, 0.f, 0.f}, rf1 = {0.f, 0.f, 0.f, 0.f};
+    f16x8 rh = {};
+    if (p.res && !transposed) {
+      if (p.res_f32) {
+        const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+        rf0 = *(const f32x4*)rp;
+        rf1 = *(const f32x4*)(rp + 4);
+      } else {
+        rh = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
+      }
+    }
+    // four slabs' loads in flight at a time (a load-add-load-add chain paid one memory latency per slab); the
+    // additions stay in slab order, so the result is bit-identical
+    for (int z0 = 0; z0 < p.ksplit; z0 += 4) {
+      f32x4 s0[4], s1[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += s0[e]; v[4 + e] += s1[e]; }
+      for (int j = 0; j < 4; ++j) {
+        if (z0 + j < p.ksplit) {
+          const float* sp = p.slab + (size_t)(z0 + j) * MN + (size_t)m * p.N + n;
+          s0[j] = *(const f32x4*)sp;
+          s1[j] = *(const f32x4*)(sp + 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (z0 + j < p.ksplit) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += s0[j][e]; v[4 + e] += s1[j][e]; }
+        }
+      }
     }
     if (p.bias) {
 #pragma unroll
@@ -868,7 +895,6 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
     }
-    const bool transposed = p.outT != nullptr && n >= p.nt0;
     if (transposed) {
       const int Ct = p.N - p.nt0;
       const int b = m / p.S, s = m - b * p.S;
@@ -877,14 +903,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
       continue;
     }
     if (p.res) {
-      if (p.res_f32) {
-        const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rp[e];
-      } else {
-        const f16x8 rr = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+      for (int e = 0; e < 4; ++e) {
+        v[e] += rf0[e] + (float)rh[e];
+        v[4 + e] += rf1[e] + (float)rh[4 + e];
       }
     }
     f16x8 o16;

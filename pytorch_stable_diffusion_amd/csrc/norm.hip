@@ -84,6 +84,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
+  // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, p.P);
+  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 4 per thread
+  constexpr int IT = 4;
+  float v[IT][8];
+  int px_[IT], c_[IT];
+  bool ok[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {               // phase A: every load of this thread in flight at once
+    const int it = tid + k * 256;
+    ok[k] = it < items;
+    const int itc = ok[k] ? it : 0;
+    px_[k] = p0 + itc / C8;
+    c_[k] = (itc % C8) * 8;
+    const bool second = c_[k] >= p.C0;
+    const void* base = second ? p.x1 : p.x0;
+    const int cs = second ? p.C1 : p.C0;
+    const int cc = second ? c_[k] - p.C0 : c_[k];
+    if (ok[k]) load8(base, p.in_f32, ((size_t)n * p.P + px_[k]) * cs + cc, v[k]);
+  }
   {
     const int g = tid & 31, sl = tid >> 5;
     float s = 0.f, q = 0.f;
@@ -112,26 +133,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     s_rstd[tid] = rsqrtf(var + p.eps);
   }
   __syncthreads();
-  const int p0 = blockIdx.x * pix_per_block;
-  const int p1 = min(p0 + pix_per_block, p.P);
-  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 4 per thread
-  constexpr int IT = 4;
-  float v[IT][8];
-  int px_[IT], c_[IT];
-  bool ok[IT];
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {               // phase A: every load of this thread in flight at once
-    const int it = tid + k * 256;
-    ok[k] = it < items;
-    const int itc = ok[k] ? it : 0;
-    px_[k] = p0 + itc / C8;
-    c_[k] = (itc % C8) * 8;
-    const bool second = c_[k] >= p.C0;
-    const void* base = second ? p.x1 : p.x0;
-    const int cs = second ? p.C1 : p.C0;
-    const int cc = second ? c_[k] - p.C0 : c_[k];
-    if (ok[k]) load8(base, p.in_f32, ((size_t)n * p.P + px_[k]) * cs + cc, v[k]);
-  }
 #pragma unroll
   for (int k = 0; k < IT; ++k) {               // phase B: normalise (+SiLU), convert, store
     if (!ok[k]) continue;
