@@ -1,5 +1,5 @@
-"""End-to-end drop-in check (-m gpu): this repo's pipeline.generate() on the GPU (native UNet loop +
-interim torch-ROCm CLIP/VAE) against the image the reference's own generate() produced on the CPU with the
+"""End-to-end drop-in check (-m gpu): this repo's pipeline.generate() on the GPU (native CLIP, UNet loop,
+VAE encoder/decoder: every model on the HIP library) against the image the reference's own generate() produced on the CPU with the
 same synthetic weights, stub tokenizer, seed and prompt (tests/golden/e2e.npz).
 Stated tolerance (north_star): pixel MAE < 1e-3 on the [0,1] float image; uint8 images may differ by a few LSB."""
 import numpy as np
