@@ -172,7 +172,7 @@ def main():
 
     # ---- 50-step image latency: the drop-in generate() end to end (CLIP x2 + 50 fused steps + VAE decode)
     image_latency = None
-    if rank == 0 and not args.no_image_latency and hw == 64:
+    if rank == 0 and world == 1 and not args.no_image_latency and hw == 64:
         from pytorch_stable_diffusion_amd import model_loader, pipeline
         from tests.stub_tokenizer import StubTokenizer
         aux = model_loader.synthetic_state_dicts(("clip", "decoder"))
@@ -202,7 +202,7 @@ def main():
 
     # ---- CPU baseline: the oracle (fp32 PyTorch-CPU port of the reference path) on this host's cores
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # rank 0 at N = 1 only (bench contract)
         from oracle import ddpm_ref, unet_ref
         if sd_cpu is None:
             from pytorch_stable_diffusion_amd import synth
