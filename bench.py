@@ -248,6 +248,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                   # ranks leave together (rank 0 ran the profiling leg meanwhile)
         dist.destroy_process_group()
 
 
