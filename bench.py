@@ -66,12 +66,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal knobs (one-GPU box): SDMI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SDMI_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device); the production path is nccl, one rank per GPU
+    if os.environ.get("SDMI_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SDMI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pytorch_stable_diffusion_amd import arch
     from pytorch_stable_diffusion_amd.ddpm import DDPMSampler
