@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
       if (co < Cout) {
         const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[co] += (float)xv[e] * (float)wv[e];
+        for (int e = 0; e < 8; e += 2)      // v_dot2_f32_f16: two fp16 products + fp32 accumulate per instruction
+          acc[co] = __builtin_amdgcn_fdot2(f16x2{xv[e], xv[e + 1]}, f16x2{wv[e], wv[e + 1]}, acc[co], false);
       }
     }
   }
