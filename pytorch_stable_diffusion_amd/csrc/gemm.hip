@@ -843,10 +843,12 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
-  const size_t total8 = (size_t)p.M * (p.N / 8);
+  const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
+  const unsigned n8 = (unsigned)(p.N / 8);
   const size_t MN = (size_t)p.M * p.N;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (size_t)gridDim.x * 256) {
-    const int m = (int)(idx / (p.N / 8)), n = (int)(idx % (p.N / 8)) * 8;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total8; idx += gridDim.x * 256u) {
+    const unsigned mq = idx / n8;
+    const int m = (int)mq, n = (int)(idx - mq * n8) * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -1095,6 +1097,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 }
 
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st) {
+  SDMI_REQUIRE((size_t)a.M * (a.N / 8) < ((size_t)1 << 31), "splitk_finalize: M*N too large");
   const size_t total8 = (size_t)a.M * (a.N / 8);
   int blocks = (int)((total8 + 255) / 256);
   if (blocks > 2048) blocks = 2048;

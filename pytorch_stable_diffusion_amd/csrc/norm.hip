@@ -53,7 +53,7 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
   float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    if ((c + e) / cpg == g0) { a0 += sum[e]; q0 += sq[e]; } else { a1 += sum[e]; q1 += sq[e]; }
+    if (c - g0 * cpg + e < cpg) { a0 += sum[e]; q0 += sq[e]; } else { a1 += sum[e]; q1 += sq[e]; }
   }
   s_part[tid * 4 + 0] = a0; s_part[tid * 4 + 1] = q0; s_part[tid * 4 + 2] = a1; s_part[tid * 4 + 3] = q1;
   __syncthreads();
@@ -92,13 +92,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   float v[IT][8];
   int px_[IT], c_[IT];
   bool ok[IT];
+  const int q_first = tid / C8, r_first = tid - q_first * C8;     // item = tid + 256 k -> (pixel, chunk) incrementally
+  const int dq = 256 / C8, dr = 256 - dq * C8;
+  int qq = q_first, rr = r_first;
 #pragma unroll
   for (int k = 0; k < IT; ++k) {               // phase A: every load of this thread in flight at once
     const int it = tid + k * 256;
     ok[k] = it < items;
-    const int itc = ok[k] ? it : 0;
-    px_[k] = p0 + itc / C8;
-    c_[k] = (itc % C8) * 8;
+    px_[k] = p0 + (ok[k] ? qq : 0);
+    c_[k] = (ok[k] ? rr : 0) * 8;
+    qq += dq; rr += dr;
+    if (rr >= C8) { rr -= C8; ++qq; }
     const bool second = c_[k] >= p.C0;
     const void* base = second ? p.x1 : p.x0;
     const int cs = second ? p.C1 : p.C0;
@@ -140,9 +144,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     const f32x4 ga = *(const f32x4*)(p.gamma + c), gb = *(const f32x4*)(p.gamma + c + 4);
     const f32x4 ba = *(const f32x4*)(p.beta + c), bb = *(const f32x4*)(p.beta + c + 4);
     f16x8 o;
+    const int g0 = c / cpg;                      // one division per item; cpg >= 4, so c+e is at most 2 groups further
+    const int r0 = c - g0 * cpg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int g = (c + e) / cpg;
+      int g = g0, rr2 = r0 + e;
+      if (rr2 >= cpg) { rr2 -= cpg; ++g; }
+      if (rr2 >= cpg) { rr2 -= cpg; ++g; }
+      if (rr2 >= cpg) ++g;
       const float gam = e < 4 ? ga[e] : gb[e - 4];
       const float bet = e < 4 ? ba[e] : bb[e - 4];
       float y = (v[k][e] - s_mean[g]) * s_rstd[g] * gam + bet;
@@ -165,12 +174,17 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   const int total = p.P * hp;
   f32x2 v[MAXP];
   float s = 0.f;
+  // slot = tid + i*NT walks (pixel, channel pair) incrementally: one integer division per thread instead of one per
+  // slot and phase (the compiler's 32-bit division is ~30 VALU instructions; there were up to 128 per thread)
+  const int px_first = tid / hp, j_first = tid - px_first * hp;
+  const int dpx = GNF_NT / hp, dj = GNF_NT - dpx * hp;
+  int px = px_first, j = j_first;
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int slot = tid + i * GNF_NT;
     v[i] = f32x2{0.f, 0.f};
     if (slot < total) {
-      const int px = slot / hp, c = g * cpg + 2 * (slot - px * hp);
+      const int c = g * cpg + 2 * j;
       const bool second = c >= p.C0;
       const void* base = second ? p.x1 : p.x0;
       const int cs = second ? p.C1 : p.C0;
@@ -179,6 +193,8 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
       else { const f16x2 h = *(const f16x2*)((const f16*)base + off); v[i] = f32x2{(float)h[0], (float)h[1]}; }
     }
     s += v[i][0] + v[i][1];
+    px += dpx; j += dj;
+    if (j >= hp) { j -= hp; ++px; }
   }
   auto block_sum = [&](float x, int which) {
 #pragma unroll
@@ -201,17 +217,20 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
     }
   }
   const float rstd = rsqrtf(block_sum(q, 1) / cnt + p.eps);
+  px = px_first; j = j_first;
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int slot = tid + i * GNF_NT;
     if (slot < total) {
-      const int px = slot / hp, c = g * cpg + 2 * (slot - px * hp);
+      const int c = g * cpg + 2 * j;
       const f32x2 ga = *(const f32x2*)(p.gamma + c), be = *(const f32x2*)(p.beta + c);
       float y0 = (v[i][0] - mean) * rstd * ga[0] + be[0];
       float y1 = (v[i][1] - mean) * rstd * ga[1] + be[1];
       if (p.silu) { y0 = y0 / (1.f + __expf(-y0)); y1 = y1 / (1.f + __expf(-y1)); }
       *(f16x2*)(p.y + ((size_t)n * p.P + px) * C + c) = f16x2{(f16)y0, (f16)y1};
     }
+    px += dpx; j += dj;
+    if (j >= hp) { j -= hp; ++px; }
   }
 }
 
@@ -301,7 +320,7 @@ int sdmi_gn_launches(const GnArgs& a) {
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
   SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "groupnorm: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
-  SDMI_REQUIRE(C / 8 <= 320, "groupnorm: C=%d too large (max 2560)", C);
+  SDMI_REQUIRE(C / 8 <= 320 && C >= 128, "groupnorm: C=%d out of range (128..2560)", C);
   SDMI_REQUIRE(a.partial && a.y && a.x0 && a.gamma && a.beta, "groupnorm: null pointer");
   SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
   if (sdmi_gn_launches(a) == 1) {
