@@ -84,13 +84,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int la
                                                         const float* bias, void* out, int out_f32, f16* out16,
                                                         int B, int H, int W, int Cout, int Cin) {
   const int C8 = Cout / 8;
-  const size_t total = (size_t)B * H * W * C8;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int c8 = (int)(idx % C8);
-    const size_t pix = idx / C8;
-    const int ow = (int)(pix % W);
-    const int oh = (int)((pix / W) % H);
-    const int b = (int)(pix / ((size_t)W * H));
+  const unsigned total = (unsigned)B * H * W * C8;                     // < 2^31: 32-bit index math
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned pix = idx / (unsigned)C8;
+    const int c8 = (int)(idx - pix * C8);
+    const unsigned prow = pix / (unsigned)W;
+    const int ow = (int)(pix - prow * W);
+    const int b = (int)(prow / (unsigned)H);
+    const int oh = (int)(prow - (unsigned)b * H);
     const int lb = lat_batch == 1 ? 0 : b;
     float acc[8];
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int la
     f16x8 o16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o16[e] = (f16)acc[e];
-    const size_t off = pix * Cout + c8 * 8;
+    const size_t off = (size_t)pix * Cout + c8 * 8;
     if (out_f32) {
       float* op = (float*)out + off;
 #pragma unroll
@@ -139,12 +140,13 @@ __global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout,
 __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16* w, const float* bias, float* out,
                                                          int B, int H, int W, int Cin, int Cout) {
   const int lane = threadIdx.x & 63;
-  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t npix = (size_t)B * H * W;
+  const unsigned pix = blockIdx.x * 4u + (threadIdx.x >> 6);          // < 2^31 pixels: 32-bit index math
+  const unsigned npix = (unsigned)B * H * W;
   if (pix >= npix) return;
-  const int ow = (int)(pix % W);
-  const int oh = (int)((pix / W) % H);
-  const int b = (int)(pix / ((size_t)W * H));
+  const unsigned prow = pix / (unsigned)W;
+  const int ow = (int)(pix - prow * W);
+  const int b = (int)(prow / (unsigned)H);
+  const int oh = (int)(prow - (unsigned)b * H);
   const int C8 = Cin / 8;
   const int items = 9 * C8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -437,6 +439,7 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
                           int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st) {
   SDMI_REQUIRE(Cout % 8 == 0 && Cin >= 1 && Cin <= 4, "stem conv: Cout=%d Cin=%d", Cout, Cin);
   const size_t total = (size_t)B * H * W * (Cout / 8);
+  SDMI_REQUIRE(total < ((size_t)1 << 31), "stem conv: too many outputs");
   hipLaunchKernelGGL(stem_conv_kernel, dim3(nblocks(total)), dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32,
                      out16, B, H, W, Cout, Cin);
   SDMI_CHECK_HIP(hipGetLastError());
@@ -447,6 +450,7 @@ int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float*
                            int Cout, hipStream_t st) {
   SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "final conv: Cin=%d Cout=%d", Cin, Cout);
   const size_t npix = (size_t)B * H * W;
+  SDMI_REQUIRE(npix < ((size_t)1 << 31), "final conv: too many pixels");
   hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
