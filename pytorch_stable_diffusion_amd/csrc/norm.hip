@@ -315,7 +315,7 @@ int sdmi_gn_launches(const GnArgs& a) {
   static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 256;   // measured: 64 blocks cannot pull larger maps fast enough
   const int C = a.C0 + a.C1, cpg = C / 32;
   const long pairs = ((long)a.P * (cpg / 2) + GNF_NT - 1) / GNF_NT;
-  return (cpg % 2 == 0 && a.C0 % 2 == 0 && a.P <= max_px && pairs <= 64) ? 1 : 2;
+  return (cpg % 2 == 0 && a.C0 % 2 == 0 && a.P <= max_px && pairs <= 24) ? 1 : 2;
 }
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
@@ -328,8 +328,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
       const long pairs = ((long)a.P * (C / 64) + GNF_NT - 1) / GNF_NT;
       const dim3 grid(32, a.B), block(GNF_NT);
       if (pairs <= 8) hipLaunchKernelGGL(gn_fused_kernel<8>, grid, block, 0, st, a);
-      else if (pairs <= 24) hipLaunchKernelGGL(gn_fused_kernel<24>, grid, block, 0, st, a);
-      else hipLaunchKernelGGL(gn_fused_kernel<64>, grid, block, 0, st, a);
+      else hipLaunchKernelGGL(gn_fused_kernel<24>, grid, block, 0, st, a);
       SDMI_CHECK_HIP(hipGetLastError());
       return SDMI_OK;
     }
