@@ -157,7 +157,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         }
         if (p.act == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     }
     if (p.act == 1) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
     }
     if (transposed) {
       const int Ct = p.N - p.nt0;

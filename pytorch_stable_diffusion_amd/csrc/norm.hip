@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
       const float gam = e < 4 ? ga[e] : gb[e - 4];
       const float bet = e < 4 ? ba[e] : bb[e - 4];
       float y = (v[k][e] - s_mean[g]) * s_rstd[g] * gam + bet;
-      if (p.silu) y = y / (1.f + __expf(-y));
+      if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));     // v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division
       o[e] = (f16)y;
     }
     *(f16x8*)(p.y + ((size_t)n * p.P + px_[k]) * C + c) = o;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
       const f32x2 ga = *(const f32x2*)(p.gamma + c), be = *(const f32x2*)(p.beta + c);
       float y0 = (v[i][0] - mean) * rstd * ga[0] + be[0];
       float y1 = (v[i][1] - mean) * rstd * ga[1] + be[1];
-      if (p.silu) { y0 = y0 / (1.f + __expf(-y0)); y1 = y1 / (1.f + __expf(-y1)); }
+      if (p.silu) { y0 = y0 * __builtin_amdgcn_rcpf(1.f + __expf(-y0)); y1 = y1 * __builtin_amdgcn_rcpf(1.f + __expf(-y1)); }
       *(f16x2*)(p.y + ((size_t)n * p.P + px) * C + c) = f16x2{(f16)y0, (f16)y1};
     }
     px += dpx; j += dj;
