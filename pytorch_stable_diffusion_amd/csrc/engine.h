@@ -377,7 +377,7 @@ struct Engine {
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < 5; ++rep) {
           SDMI_CHECK_HIP(hipEventRecord(e0, st));
           int rc = sdmi_launch_gemm(a, cfg, st);
           if (rc != SDMI_OK) return rc;
