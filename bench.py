@@ -10,6 +10,7 @@ collective is the start-up weight broadcast + the timing reduction.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N          (no launcher: starts the N ranks itself, before touching any GPU)
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -40,7 +41,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image-latency", action="store_true", help="skip the end-to-end generate() latency leg")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-config1", action="store_true",
+                    help="also time BASELINE configs[0] end to end on the host CPU (oracle CLIP x2 + 20 CFG steps + VAE "
+                         "decoder, minutes of CPU time; not part of the default run)")
     return ap.parse_args()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of THIS process (which has not
+    touched the GPU and never will), relay their output, exit with their code.  No exec of a GPU-initialised process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
 
 
 def synth_weights_flat(manifest, device, rank, world):
@@ -61,9 +78,12 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # rehearsal knobs (one-GPU box): SDMI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SDMI_BENCH_BACKEND=gloo
@@ -89,9 +109,8 @@ def main():
     man = arch.diffusion_manifest()
     t0 = time.time()
     state, sd_cpu = synth_weights_flat(man, dev, rank, world)
-    model = Diffusion(stream_f32=not args.stream_f16)
-    model.load_state_dict(state, strict=True)
-    model._device = dev          # tensors already live on this rank's GPU
+    model = Diffusion(stream_f32=not args.stream_f16).to(dev)
+    model.load_state_dict(state, strict=True)      # views of the broadcast buffer, already on this rank's GPU
     h = model.handle()
     t_load = time.time() - t0
 

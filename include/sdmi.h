@@ -100,6 +100,11 @@ int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_c
 /* Number of kernel launches enqueued by the last sdmi_unet_forward, and bytes of packed weights. */
 int sdmi_unet_last_launch_count(const sdmi_unet* u);
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);
+/* GEMM shapes this handle had to time itself so far (0 when every shape came from the plan tables: the table
+ * shipped as <package>/plans/gfx950.txt or the per-library cache ~/.cache/sdmi/plans-<hash>.txt), and the HIP
+ * device the handle lives on.  Every entry point that launches work returns -22 unless that device is current. */
+int sdmi_unet_tuned_shapes(const sdmi_unet* u);
+int sdmi_unet_device(const sdmi_unet* u);
 
 /* ---- VAE decoder (next row after the hot path; reference sd/decoder.py:342-374) ------------------
  * tensors: the 136-entry state dict of VAE_Decoder (keys "0.weight" ... "25.bias",

@@ -1,0 +1,110 @@
+"""Oracle: CLIP text encoder and VAE encoder / decoder, functional fp32 restatement (TEST INFRASTRUCTURE ONLY --
+see oracle/__init__.py; nothing under pytorch_stable_diffusion_amd/ may import this).
+
+State dicts use the reference's key names (sd/model_converter.py:750-1054).  Pinned against fixtures captured from the
+imported reference (tests/golden/make_golden_aux.py -> aux.npz; tests/test_aux_models.py): CLIP <= 2e-5, decoder and
+encoder <= 5e-5 max-abs.  Reference quirks reproduced:
+  Q3  VAE_AttentionBlock never applies its GroupNorm          (sd/decoder.py:31,34-73)
+  Q4  ``x.transpose(-1, 2)`` is a no-op on a 3-D tensor and the (n, h*w, c) attention output is REINTERPRETED as
+      (n, c, h, w) by ``view``                                 (sd/decoder.py:62,67)
+  in-place ``x /= 0.18215`` on the caller's latents            (sd/decoder.py:364)
+  CLIP masks BEFORE scaling by 1/sqrt(d)                       (sd/attention.py:58-66)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from pytorch_stable_diffusion_amd import arch
+
+SD = Dict[str, torch.Tensor]
+
+
+def _res(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """VAE_ResidualBlock (sd/decoder.py:148-190)."""
+    h = F.group_norm(x, 32, sd[f"{p}.groupnorm_1.weight"], sd[f"{p}.groupnorm_1.bias"])
+    h = F.conv2d(F.silu(h), sd[f"{p}.conv_1.weight"], sd[f"{p}.conv_1.bias"], padding=1)
+    h = F.group_norm(h, 32, sd[f"{p}.groupnorm_2.weight"], sd[f"{p}.groupnorm_2.bias"])
+    h = F.conv2d(F.silu(h), sd[f"{p}.conv_2.weight"], sd[f"{p}.conv_2.bias"], padding=1)
+    w = sd.get(f"{p}.residual_layer.weight")
+    return h + (x if w is None else F.conv2d(x, w, sd[f"{p}.residual_layer.bias"]))
+
+
+def _attn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """VAE_AttentionBlock (sd/decoder.py:34-73) with quirks Q3 (no groupnorm) and Q4 (reinterpreting view)."""
+    n, c, h, w = x.shape
+    t = x.reshape(n, c, h * w).transpose(1, 2)                       # (n, hw, c)
+    qkv = F.linear(t, sd[f"{p}.attention.in_proj.weight"], sd[f"{p}.attention.in_proj.bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(c), dim=-1) @ v          # single head
+    o = F.linear(a, sd[f"{p}.attention.out_proj.weight"], sd[f"{p}.attention.out_proj.bias"])
+    return o.contiguous().view(n, c, h, w) + x                        # Q4: memory reinterpretation
+
+
+def _run(sd: SD, stages, x: torch.Tensor, pad_stride2: bool) -> torch.Tensor:
+    """The nn.Sequential walk of sd/encoder.py:95-131 / sd/decoder.py:342-374 over the stage table."""
+    for i, op in enumerate(stages):
+        p = str(i)
+        if op[0] == "conv":
+            _, _cin, _cout, _ks, stride, pad = op
+            if pad_stride2 and stride == 2:
+                x = F.pad(x, (0, 1, 0, 1))                            # asymmetric pad, sd/encoder.py:120-122
+            x = F.conv2d(x, sd[f"{p}.weight"], sd[f"{p}.bias"], stride=stride, padding=pad)
+        elif op[0] == "res":
+            x = _res(sd, p, x)
+        elif op[0] == "attn":
+            x = _attn(sd, p, x)
+        elif op[0] == "up":
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        elif op[0] == "gn":
+            x = F.group_norm(x, 32, sd[f"{p}.weight"], sd[f"{p}.bias"])
+        elif op[0] == "silu":
+            x = F.silu(x)
+    return x
+
+
+@torch.no_grad()
+def vae_decode(sd: SD, latents: torch.Tensor) -> torch.Tensor:
+    """(B,4,h,w) -> (B,3,8h,8w); divides the caller's tensor by 0.18215 IN PLACE like sd/decoder.py:364."""
+    latents /= 0.18215
+    return _run(sd, arch.VAE_DECODER, latents, pad_stride2=False)
+
+
+@torch.no_grad()
+def vae_encode(sd: SD, image: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """(B,3,H,W) in [-1,1], noise (B,4,H/8,W/8) -> latents (sd/encoder.py:95-155: clamp, exp, sqrt, reparameterise,
+    x0.18215)."""
+    x = _run(sd, arch.VAE_ENCODER, image, pad_stride2=True)
+    mean, log_variance = torch.chunk(x, 2, dim=1)
+    log_variance = torch.clamp(log_variance, -30, 20)
+    stdev = log_variance.exp().sqrt()
+    x = mean + stdev * noise
+    x *= 0.18215
+    return x
+
+
+@torch.no_grad()
+def clip_forward(sd: SD, tokens: torch.Tensor) -> torch.Tensor:
+    """(B,77) int64 -> (B,77,768).  sd/clip.py:227-261: token + position embedding, 12 pre-norm layers (12 heads,
+    causal mask applied before the 1/sqrt(d) scale, quick-GELU x*sigmoid(1.702x) sd/clip.py:170), final LayerNorm."""
+    tokens = tokens.type(torch.long)
+    x = F.embedding(tokens, sd["embedding.token_embedding.weight"]) + sd["embedding.position_embedding"]
+    b, s, c = x.shape
+    hd = c // arch.CLIP_HEADS
+    mask = torch.ones((s, s), dtype=torch.bool, device=x.device).triu(1)
+    for i in range(arch.CLIP_LAYERS):
+        p = f"layers.{i}"
+        h = F.layer_norm(x, (c,), sd[f"{p}.layernorm_1.weight"], sd[f"{p}.layernorm_1.bias"])
+        qkv = F.linear(h, sd[f"{p}.attention.in_proj.weight"], sd[f"{p}.attention.in_proj.bias"])
+        q, k, v = (t.reshape(b, s, arch.CLIP_HEADS, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        w = (q @ k.transpose(-1, -2)).masked_fill(mask, float("-inf")) / math.sqrt(hd)   # mask before scale
+        o = (torch.softmax(w, dim=-1) @ v).transpose(1, 2).reshape(b, s, c)
+        x = x + F.linear(o, sd[f"{p}.attention.out_proj.weight"], sd[f"{p}.attention.out_proj.bias"])
+        h = F.layer_norm(x, (c,), sd[f"{p}.layernorm_2.weight"], sd[f"{p}.layernorm_2.bias"])
+        h = F.linear(h, sd[f"{p}.linear_1.weight"], sd[f"{p}.linear_1.bias"])
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + F.linear(h, sd[f"{p}.linear_2.weight"], sd[f"{p}.linear_2.bias"])
+    return F.layer_norm(x, (c,), sd["layernorm.weight"], sd["layernorm.bias"])

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "sdmi_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "sdmi_unet_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
+    "sdmi_unet_tuned_shapes": (C.c_int, [C.c_void_p]),
+    "sdmi_unet_device": (C.c_int, [C.c_void_p]),
     "sdmi_vae_decoder_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sdmi_vae_destroy": (None, [C.c_void_p]),
     "sdmi_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -129,8 +131,37 @@ def check(rc: int, what: str = "") -> None:
     raise SdmiError(f"{what}: rc={rc}: {msg}")
 
 
-def cur_stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def cur_stream(device=None) -> C.c_void_p:
+    """The current torch stream of ``device`` (default: the current device) as a hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _state_device(state: Dict[str, torch.Tensor]) -> torch.device:
+    devs = {v.device for v in state.values()}
+    if len(devs) != 1 or next(iter(devs)).type != "cuda":
+        raise ValueError(f"weights must all live on ONE cuda device, got {sorted(map(str, devs))}")
+    return next(iter(devs))
+
+
+class _DeviceBound:
+    """Base of the native handles.  A handle's packed weights, arena and plans live on ONE device (the device of
+    its weights); every native call runs with that device current and on that device's current torch stream, and
+    every tensor argument must live there -- otherwise the kernels would be launched on another GPU's stream with
+    pointers it cannot reach (a memory fault, not an error code).  The library re-checks the current device
+    itself (Engine::enter) and returns -22 on a mismatch."""
+
+    _dev: torch.device
+
+    def _guard(self):
+        return torch.cuda.device(self._dev)
+
+    def _stream(self) -> C.c_void_p:
+        return cur_stream(self._dev)
+
+    def _on_dev(self, *tensors):
+        for t in tensors:
+            if t is not None and t.device != self._dev:
+                raise ValueError(f"tensor on {t.device} passed to a native handle that lives on {self._dev}")
 
 
 def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -165,18 +196,20 @@ def _tensor_descs(state: Dict[str, torch.Tensor]):
     return descs, keep
 
 
-class VaeDecoderHandle:
+class VaeDecoderHandle(_DeviceBound):
     """Owns one native sdmi_vae (VAE decoder, or encoder with ``encoder=True``)."""
 
     def __init__(self, state: Dict[str, torch.Tensor], flags: int = FLAG_STREAM_F32, encoder: bool = False):
         lib = load()
         descs, keep = _tensor_descs(state)
+        self._dev = _state_device(state)
         h = C.c_void_p()
-        torch.cuda.synchronize()
-        if encoder:
-            check(lib.sdmi_vae_encoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_encoder_create")
-        else:
-            check(lib.sdmi_vae_decoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_decoder_create")
+        with self._guard():
+            torch.cuda.synchronize(self._dev)
+            if encoder:
+                check(lib.sdmi_vae_encoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_encoder_create")
+            else:
+                check(lib.sdmi_vae_decoder_create(descs, len(state), flags, C.byref(h)), "sdmi_vae_decoder_create")
         del keep
         self._h, self._lib = h, lib
 
@@ -193,19 +226,23 @@ class VaeDecoderHandle:
 
     def encode(self, image: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         assert image.is_cuda and image.dtype == torch.float32 and image.dim() == 4 and image.shape[1] == 3
+        self._on_dev(image)
         image, noise = image.contiguous(), noise.to(image.device, torch.float32).contiguous()
         b, _, hh, ww = image.shape
         assert tuple(noise.shape) == (b, 4, hh // 8, ww // 8)
-        out = torch.empty((b, 4, hh // 8, ww // 8), dtype=torch.float32, device=image.device)
-        check(self._lib.sdmi_vae_encode(self._h, ptr(image), ptr(noise), ptr(out), b, hh, ww, cur_stream()), "sdmi_vae_encode")
+        with self._guard():
+            out = torch.empty((b, 4, hh // 8, ww // 8), dtype=torch.float32, device=self._dev)
+            check(self._lib.sdmi_vae_encode(self._h, ptr(image), ptr(noise), ptr(out), b, hh, ww, self._stream()), "sdmi_vae_encode")
         return out
 
     def decode(self, latents: torch.Tensor) -> torch.Tensor:
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.dim() == 4 and latents.shape[1] == 4
+        self._on_dev(latents)
         latents = latents.contiguous()
         b, _, h, w = latents.shape
-        out = torch.empty((b, 3, 8 * h, 8 * w), dtype=torch.float32, device=latents.device)
-        check(self._lib.sdmi_vae_decode(self._h, ptr(latents), ptr(out), b, h, w, cur_stream()), "sdmi_vae_decode")
+        with self._guard():
+            out = torch.empty((b, 3, 8 * h, 8 * w), dtype=torch.float32, device=self._dev)
+            check(self._lib.sdmi_vae_decode(self._h, ptr(latents), ptr(out), b, h, w, self._stream()), "sdmi_vae_decode")
         return out
 
     @property
@@ -213,15 +250,17 @@ class VaeDecoderHandle:
         return self._lib.sdmi_vae_last_launch_count(self._h)
 
 
-class ClipHandle:
+class ClipHandle(_DeviceBound):
     """Owns one native sdmi_clip (CLIP text encoder)."""
 
     def __init__(self, state: Dict[str, torch.Tensor], flags: int = 0):
         lib = load()
         descs, keep = _tensor_descs(state)
+        self._dev = _state_device(state)
         h = C.c_void_p()
-        torch.cuda.synchronize()
-        check(lib.sdmi_clip_create(descs, len(state), flags, C.byref(h)), "sdmi_clip_create")
+        with self._guard():
+            torch.cuda.synchronize(self._dev)
+            check(lib.sdmi_clip_create(descs, len(state), flags, C.byref(h)), "sdmi_clip_create")
         del keep
         self._h, self._lib = h, lib
 
@@ -238,9 +277,11 @@ class ClipHandle:
 
     def encode(self, tokens: torch.Tensor) -> torch.Tensor:
         assert tokens.is_cuda and tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.shape[1] == 77
+        self._on_dev(tokens)
         tokens = tokens.contiguous()
-        out = torch.empty((tokens.shape[0], 77, 768), dtype=torch.float32, device=tokens.device)
-        check(self._lib.sdmi_clip_encode(self._h, ptr(tokens), ptr(out), tokens.shape[0], cur_stream()), "sdmi_clip_encode")
+        with self._guard():
+            out = torch.empty((tokens.shape[0], 77, 768), dtype=torch.float32, device=self._dev)
+            check(self._lib.sdmi_clip_encode(self._h, ptr(tokens), ptr(out), tokens.shape[0], self._stream()), "sdmi_clip_encode")
         return out
 
     @property
@@ -248,15 +289,17 @@ class ClipHandle:
         return self._lib.sdmi_clip_last_launch_count(self._h)
 
 
-class UNetHandle:
+class UNetHandle(_DeviceBound):
     """Owns one native sdmi_unet.  ``state`` maps the reference's state-dict keys to CUDA tensors."""
 
     def __init__(self, state: Dict[str, torch.Tensor], flags: int = 0):
         lib = load()
         descs, keep = _tensor_descs(state)
+        self._dev = _state_device(state)
         h = C.c_void_p()
-        torch.cuda.synchronize()
-        check(lib.sdmi_unet_create(descs, len(state), flags, C.byref(h)), "sdmi_unet_create")
+        with self._guard():
+            torch.cuda.synchronize(self._dev)
+            check(lib.sdmi_unet_create(descs, len(state), flags, C.byref(h)), "sdmi_unet_create")
         del keep
         self._h = h
         self._lib = lib
@@ -275,46 +318,56 @@ class UNetHandle:
 
     def set_context(self, ctx: torch.Tensor):
         assert ctx.is_cuda and ctx.dtype == torch.float32 and ctx.dim() == 3 and ctx.shape[2] == 768
+        self._on_dev(ctx)
         ctx = ctx.contiguous()
-        check(self._lib.sdmi_unet_set_context(self._h, ptr(ctx), ctx.shape[0], ctx.shape[1], cur_stream()),
-              "sdmi_unet_set_context")
+        with self._guard():
+            check(self._lib.sdmi_unet_set_context(self._h, ptr(ctx), ctx.shape[0], ctx.shape[1], self._stream()),
+                  "sdmi_unet_set_context")
 
     def set_schedule(self, temb: torch.Tensor):
         assert temb.is_cuda and temb.dtype == torch.float32 and temb.dim() == 2 and temb.shape[1] == 320
+        self._on_dev(temb)
         temb = temb.contiguous()
-        check(self._lib.sdmi_unet_set_schedule(self._h, ptr(temb), temb.shape[0], cur_stream()),
-              "sdmi_unet_set_schedule")
+        with self._guard():
+            check(self._lib.sdmi_unet_set_schedule(self._h, ptr(temb), temb.shape[0], self._stream()),
+                  "sdmi_unet_set_schedule")
 
     def forward(self, latents: torch.Tensor, batch: int, temb: Optional[torch.Tensor] = None,
                 step_idx: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert latents.is_cuda and latents.dtype == torch.float32 and latents.dim() == 4 and latents.shape[1] == 4
+        self._on_dev(latents, temb, out)
         latents = latents.contiguous()
         lb, _, h, w = latents.shape
-        if out is None:
-            out = torch.empty((batch, 4, h, w), dtype=torch.float32, device=latents.device)
         if temb is not None:
             assert temb.is_cuda and temb.dtype == torch.float32 and temb.numel() == 320
             temb = temb.contiguous()
-        check(self._lib.sdmi_unet_forward(self._h, ptr(latents), lb, ptr(temb), step_idx, ptr(out), batch, h, w,
-                                          cur_stream()), "sdmi_unet_forward")
+        with self._guard():
+            if out is None:
+                out = torch.empty((batch, 4, h, w), dtype=torch.float32, device=self._dev)
+            check(self._lib.sdmi_unet_forward(self._h, ptr(latents), lb, ptr(temb), step_idx, ptr(out), batch, h, w,
+                                              self._stream()), "sdmi_unet_forward")
         return out
 
     def denoise_step(self, latents: torch.Tensor, step_idx: int, do_cfg: bool, cfg_scale: float,
                      noise: Optional[torch.Tensor], coef):
+        self._on_dev(latents, noise)
         _, _, h, w = latents.shape
         c = (C.c_float * 5)(*[float(x) for x in coef])
-        check(self._lib.sdmi_unet_denoise_step(self._h, ptr(latents), step_idx, int(do_cfg), float(cfg_scale),
-                                               ptr(noise), c, h, w, cur_stream()), "sdmi_unet_denoise_step")
+        with self._guard():
+            check(self._lib.sdmi_unet_denoise_step(self._h, ptr(latents), step_idx, int(do_cfg), float(cfg_scale),
+                                                   ptr(noise), c, h, w, self._stream()), "sdmi_unet_denoise_step")
 
     def run_block(self, prefix: str, kind: int, x0: torch.Tensor, x1: Optional[torch.Tensor] = None,
                   time: Optional[torch.Tensor] = None, arg: int = 1, out_shape=None) -> torch.Tensor:
         """x0/x1: NHWC fp32 CUDA tensors (B,H,W,C).  Returns NHWC fp32 (kind 4: NCHW (B,4,H,W))."""
+        self._on_dev(x0, x1, time)
         B, H, W, c0 = x0.shape
         c1 = 0 if x1 is None else x1.shape[3]
-        out = torch.empty(out_shape, dtype=torch.float32, device=x0.device)
-        check(self._lib.sdmi_unet_run_block(self._h, prefix.encode(), kind, arg, ptr(x0.contiguous()), c0,
-                                            ptr(None if x1 is None else x1.contiguous()), c1, B, H, W,
-                                            ptr(time), ptr(out), cur_stream()), "sdmi_unet_run_block")
+        with self._guard():
+            out = torch.empty(out_shape, dtype=torch.float32, device=self._dev)
+            check(self._lib.sdmi_unet_run_block(self._h, prefix.encode(), kind, arg, ptr(x0.contiguous()), c0,
+                                                ptr(None if x1 is None else x1.contiguous()), c1, B, H, W,
+                                                ptr(time), ptr(out), self._stream()), "sdmi_unet_run_block")
         return out
 
     def profile(self, enable: bool):
@@ -336,10 +389,23 @@ class UNetHandle:
     def weight_bytes(self) -> int:
         return self._lib.sdmi_unet_weight_bytes(self._h)
 
+    @property
+    def tuned_shapes(self) -> int:
+        """GEMM shapes this handle had to time itself (0 = every plan came from the shipped table / the cache)."""
+        return self._lib.sdmi_unet_tuned_shapes(self._h)
+
+    @property
+    def device_index(self) -> int:
+        return self._lib.sdmi_unet_device(self._h)
+
 
 def cfg_ddpm_step(eps, do_cfg, cfg_scale, latents, noise, coef, eps_out=None):
     lib = load()
     c = (C.c_float * 5)(*[float(x) for x in coef])
     n = latents.numel()
-    check(lib.sdmi_cfg_ddpm_step(ptr(eps), int(do_cfg), float(cfg_scale), ptr(latents), ptr(noise), c, n,
-                                 ptr(eps_out), cur_stream()), "sdmi_cfg_ddpm_step")
+    for t in (eps, noise, eps_out):
+        if t is not None and t.device != latents.device:
+            raise ValueError(f"cfg_ddpm_step: tensor on {t.device}, latents on {latents.device}")
+    with torch.cuda.device(latents.device):
+        check(lib.sdmi_cfg_ddpm_step(ptr(eps), int(do_cfg), float(cfg_scale), ptr(latents), ptr(noise), c, n,
+                                     ptr(eps_out), cur_stream(latents.device)), "sdmi_cfg_ddpm_step")

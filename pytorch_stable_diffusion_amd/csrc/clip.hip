@@ -74,7 +74,7 @@ void sdmi_clip_destroy(sdmi_clip* c) {
 int sdmi_clip_encode(sdmi_clip* c, const int64_t* tokens_dev, float* out_dev, int batch, void* stream) {
   if (!c || !tokens_dev || !out_dev) { sdmi_set_error("clip_encode: null argument"); return SDMI_EINVAL; }
   SDMI_REQUIRE(batch >= 1 && batch <= 64, "clip_encode: batch=%d unsupported", batch);
-  c->st = (hipStream_t)stream;
+  TRY(c->enter(stream));
   c->arena.off = 0;
   c->launches = 0;
   const int M = batch * kTok;

@@ -5,6 +5,9 @@
 #include "common.h"
 #include "../../include/sdmi.h"
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,8 +74,85 @@ struct Arena {
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;
 struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; long calls = 0; double flops = 0.0; };
 
+// ---- tuner plan store ---------------------------------------------------------------------------
+// Plans are (cfg NAME, split-K) per GEMM shape key.  Two text tables are read when an engine is created:
+//   1. the table shipped next to the library (<package>/plans/gfx950.txt, tuned once on an MI355X and committed):
+//      every process then runs the SAME plans (same summation order) and pays no tuning for the known shapes;
+//   2. the user's cache $SDMI_PLAN_CACHE_DIR (default ~/.cache/sdmi)/plans-<fnv64 of libsdmi.so>.txt, to which
+//      every newly tuned shape is appended -- keyed by the library's content hash, so a rebuilt library re-tunes.
+// SDMI_RETUNE=1 ignores both (and still appends to the cache file); a line is "k0 .. k9 cfgname ksplit us".
+struct PlanStore {
+  std::map<ShapeKey, std::pair<std::string, std::pair<int, float>>> table;   // key -> (cfg name, (ksplit, us))
+  std::string cache_path;
+  bool loaded = false;
+
+  static std::string lib_path() {
+    Dl_info info;
+    if (dladdr((void*)&sdmi_last_error, &info) && info.dli_fname) return info.dli_fname;
+    return "";
+  }
+  static unsigned long long fnv_file(const std::string& path) {
+    unsigned long long h = 1469598103934665603ull;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0)
+      for (size_t i = 0; i < n; ++i) { h ^= buf[i]; h *= 1099511628211ull; }
+    fclose(f);
+    return h;
+  }
+  void read_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+      if (line[0] == '#') continue;
+      int k[10], ks;
+      char name[64];
+      float us;
+      if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %63s %d %f", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7],
+                 &k[8], &k[9], name, &ks, &us) != 13) continue;
+      table[ShapeKey(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9])] = {name, {ks, us}};
+    }
+    fclose(f);
+  }
+  void load() {
+    if (loaded) return;
+    loaded = true;
+    const std::string lib = lib_path();
+    const char* dir = getenv("SDMI_PLAN_CACHE_DIR");
+    std::string d = dir ? dir : (getenv("HOME") ? std::string(getenv("HOME")) + "/.cache/sdmi" : "/tmp/sdmi-cache");
+    char hash[32];
+    snprintf(hash, sizeof(hash), "%016llx", fnv_file(lib));
+    (void)mkdir(d.substr(0, d.rfind('/')).c_str(), 0755);
+    (void)mkdir(d.c_str(), 0755);
+    cache_path = d + "/plans-" + hash + ".txt";
+    if (getenv("SDMI_RETUNE")) return;
+    const char* shipped = getenv("SDMI_PLAN_FILE");
+    if (shipped) read_file(shipped);
+    else if (!lib.empty()) {
+      const size_t s1 = lib.rfind('/');
+      const size_t s2 = s1 == std::string::npos ? s1 : lib.rfind('/', s1 - 1);
+      if (s2 != std::string::npos) read_file(lib.substr(0, s2) + "/plans/gfx950.txt");
+    }
+    read_file(cache_path);            // the user's own tuning wins over the shipped table
+  }
+  void append(const ShapeKey& k, const char* name, int ksplit, float us) {
+    table[k] = {name, {ksplit, us}};
+    if (cache_path.empty()) return;
+    FILE* f = fopen(cache_path.c_str(), "a");
+    if (!f) return;
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %s %d %.2f\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k),
+            std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), std::get<8>(k), std::get<9>(k), name, ksplit, us);
+    fclose(f);
+  }
+};
+inline PlanStore& plan_store() { static PlanStore s; return s; }
+
 struct Engine {
   int flags = 0;
+  int device = -1;            // HIP device the handle (weights, arena, plans) lives on
   bool stream_f32 = false, partial = false, tune = true;
   std::vector<void*> owned;   // hipMalloc'd blocks
   int64_t weight_bytes = 0;
@@ -105,6 +185,7 @@ struct Engine {
   float* gn_partial = nullptr;
   float* eps_buf = nullptr; size_t eps_elems = 0;
   std::map<ShapeKey, Plan> plans;
+  int tuned_shapes = 0;       // shapes this handle had to time itself (not found in the plan store)
   int launches = 0;
   hipStream_t st = nullptr;
   // optional per-launch HIP-event profiling (bench roofline): class 0 = igemm, 1 = attention, 2 = other
@@ -123,8 +204,22 @@ struct Engine {
     (void)hipEventRecord(prof.back().e1, st);
   }
 
+  Engine() { (void)hipGetDevice(&device); }
   ~Engine() {
     for (void* p : owned) (void)hipFree(p);
+  }
+
+  // Every entry point that launches work calls this first: the handle's memory lives on `device`, and a launch
+  // issued while another device is current would run there on pointers it cannot reach (a GPU fault, not an
+  // error code).  The caller must make the handle's device current (hipSetDevice / torch.cuda.device).
+  int enter(void* stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) {
+      sdmi_set_error("handle lives on HIP device %d but device %d is current", device, cur);
+      return SDMI_EINVAL;
+    }
+    st = (hipStream_t)stream;
+    return SDMI_OK;
   }
 
   template <class T>
@@ -313,11 +408,28 @@ struct Engine {
   int gemm(GemmArgs a, RowStat* rs = nullptr) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr), a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr),
+                 a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
       Plan pl;
-      if (tune) TRY(tune_gemm(a, &pl));
+      if (tune) {
+        PlanStore& ps = plan_store();
+        ps.load();
+        auto st_it = ps.table.find(key);
+        bool have = false;
+        if (st_it != ps.table.end()) {          // stored plan: valid only if this build still has the config
+          for (int c = 0; c < sdmi_gemm_num_cfgs() && !have; ++c)
+            if (st_it->second.first == sdmi_gemm_cfg_name(c) && sdmi_gemm_cfg_applicable(a, c)) {
+              pl.cfg = c; pl.ksplit = st_it->second.second.first; pl.us = st_it->second.second.second; have = true;
+            }
+        }
+        if (!have) {
+          TRY(tune_gemm(a, &pl));
+          ++tuned_shapes;
+          if (pl.cfg >= 0) ps.append(key, sdmi_gemm_cfg_name(pl.cfg), pl.ksplit, pl.us);
+        }
+      }
       it = plans.emplace(key, pl).first;
     }
     a.ksplit = it->second.ksplit;
@@ -527,7 +639,7 @@ struct Engine {
       sdmi_set_error("attn_block: context not set for batch %d (sdmi_unet_set_context)", x.B);
       return SDMI_EINVAL;
     }
-    const int B = x.B, S = x.H * x.W, C = w.C, M = x.M();
+    const int B = x.B, S = x.H * x.W, C = w.C;
     const int Spad = ((S + 63) / 64) * 64;
     Act t0, s0, u, qk, ao, s1, q2, s2, g;
     TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));

@@ -174,7 +174,7 @@ int export_act(sdmi_unet* u, const Act& a, float* out) {
 extern "C" {
 
 const char* sdmi_last_error(void) { return g_err; }
-int sdmi_version(void) { return 100; }
+int sdmi_version(void) { return 200; }
 
 int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_unet** out) {
   if (!tensors || !out || n_tensors <= 0) { sdmi_set_error("sdmi_unet_create: bad arguments"); return SDMI_EINVAL; }
@@ -235,7 +235,7 @@ void sdmi_unet_destroy(sdmi_unet* u) {
 int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_tokens, void* stream) {
   if (!u || !ctx_dev) { sdmi_set_error("set_context: null argument"); return SDMI_EINVAL; }
   SDMI_REQUIRE(batch >= 1 && batch <= 16 && n_tokens >= 1 && n_tokens <= kCtxPad, "set_context: batch=%d tokens=%d unsupported (tokens <= %d)", batch, n_tokens, kCtxPad);
-  u->st = (hipStream_t)stream;
+  TRY(u->enter(stream));
   if (u->ctx_batch != batch || !u->ctx16) {
     TRY(u->dmalloc(&u->ctx16, (size_t)batch * kCtxPad * kCtx * 2));
     u->ctxK.clear();
@@ -273,7 +273,7 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
 
 int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, void* stream) {
   if (!u || !temb_dev || n_steps < 1) { sdmi_set_error("set_schedule: bad arguments"); return SDMI_EINVAL; }
-  u->st = (hipStream_t)stream;
+  TRY(u->enter(stream));
   TRY(u->compute_timevecs(temb_dev, n_steps, u->timevec));
   u->n_steps = n_steps;
   return SDMI_OK;
@@ -285,7 +285,7 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
   SDMI_REQUIRE(latent_batch == batch || latent_batch == 1, "forward: latent_batch=%d vs batch=%d", latent_batch, batch);
   SDMI_REQUIRE(h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "forward: latent size %dx%d must be multiples of 8", h, w);
   SDMI_REQUIRE(u->has_stem && u->has_final && u->has_time, "forward: incomplete weights (handle created with SDMI_FLAG_PARTIAL?)");
-  u->st = (hipStream_t)stream;
+  TRY(u->enter(stream));
   u->launches = 0;
   u->arena.off = 0;
   const float* tv;
@@ -347,7 +347,7 @@ int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, con
                         const float* x1_dev, int c1, int batch, int h, int w, const float* time_dev, float* out_dev,
                         void* stream) {
   if (!u || !prefix || !x0_dev || !out_dev) { sdmi_set_error("run_block: null argument"); return SDMI_EINVAL; }
-  u->st = (hipStream_t)stream;
+  TRY(u->enter(stream));
   u->arena.off = 0;
   u->launches = 0;
   Act x0, x1, y;
@@ -401,6 +401,8 @@ int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_c
 }
 
 int sdmi_unet_last_launch_count(const sdmi_unet* u) { return u ? u->launches : 0; }
+int sdmi_unet_tuned_shapes(const sdmi_unet* u) { return u ? u->tuned_shapes : 0; }
+int sdmi_unet_device(const sdmi_unet* u) { return u ? u->device : -1; }
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u) { return u ? u->weight_bytes : 0; }
 
 // ---- kernel-level entry points --------------------------------------------------------------

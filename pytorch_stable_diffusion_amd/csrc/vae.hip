@@ -213,7 +213,7 @@ int sdmi_vae_encode(sdmi_vae* v, const float* image_dev, const float* noise_dev,
   if (!v || !image_dev || !noise_dev || !latents_dev) { sdmi_set_error("vae_encode: null argument"); return SDMI_EINVAL; }
   SDMI_REQUIRE(v->is_encoder, "vae_encode: handle is a decoder");
   SDMI_REQUIRE(batch >= 1 && batch <= 8 && H % 64 == 0 && W % 64 == 0 && H >= 64 && W >= 64, "vae_encode: batch=%d H=%d W=%d unsupported", batch, H, W);
-  v->st = (hipStream_t)stream;
+  TRY(v->enter(stream));
   v->arena.off = 0;
   v->launches = 0;
   Act x;
@@ -268,7 +268,7 @@ int sdmi_vae_decode(sdmi_vae* v, const float* latents_dev, float* image_dev, int
   if (!v || !latents_dev || !image_dev) { sdmi_set_error("vae_decode: null argument"); return SDMI_EINVAL; }
   SDMI_REQUIRE(!v->is_encoder, "vae_decode: handle is an encoder");
   SDMI_REQUIRE(batch >= 1 && batch <= 8 && h >= 8 && w >= 8 && (h * w) % 64 == 0, "vae_decode: batch=%d h=%d w=%d unsupported", batch, h, w);
-  v->st = (hipStream_t)stream;
+  TRY(v->enter(stream));
   v->arena.off = 0;
   v->launches = 0;
   const size_t nlat = (size_t)batch * 4 * h * w;

@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 
 from . import arch
+from ._util import normalize_device
 
 
 class Diffusion:
@@ -37,12 +38,12 @@ class Diffusion:
             if k in state:
                 if tuple(state[k].shape) != tuple(shape):
                     raise RuntimeError(f"size mismatch for {k}: {tuple(state[k].shape)} vs {tuple(shape)}")
-                self._state[k] = state[k].detach()
+                self._state[k] = state[k].detach().to(self._device)      # like nn.Module: loaded INTO the model's device
         self._drop_handle()
         return self
 
     def to(self, device):
-        device = torch.device(device)
+        device = normalize_device(device)
         if device != self._device:
             # fp16 copies on the GPU (the packer casts anyway); CPU copies stay as given
             for k in list(self._state.keys()):

@@ -21,9 +21,8 @@ def preload_models_from_state_dicts(state_dicts: Dict[str, Dict[str, torch.Tenso
     encoder.load_state_dict(state_dicts["encoder"], strict=True)
     decoder = VAE_Decoder().to(device)
     decoder.load_state_dict(state_dicts["decoder"], strict=True)
-    diffusion = Diffusion()
+    diffusion = Diffusion().to(device)
     diffusion.load_state_dict(state_dicts["diffusion"], strict=True)
-    diffusion.to(device)
     clip = CLIP().to(device)
     clip.load_state_dict(state_dicts["clip"], strict=True)
     return {"clip": clip, "encoder": encoder, "decoder": decoder, "diffusion": diffusion}

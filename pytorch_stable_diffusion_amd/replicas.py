@@ -86,3 +86,191 @@ def gather_images(img: torch.Tensor, dst: int = 0, group=None) -> Optional[List[
     bufs = [torch.empty_like(img) for _ in range(world)] if dist.get_rank(group) == dst else None
     dist.gather(img, bufs, dst=dst, group=group)
     return bufs
+
+
+# =====================================================================================================================
+# generate()-level launcher: BASELINE config 4 ("batch of 8 independent prompts, 512x512, 50 steps, sharded 1-per-GPU")
+#
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+#       -m pytorch_stable_diffusion_amd.replicas --prompts-file prompts.txt --ckpt v1-5-pruned-emaonly.ckpt \
+#       --vocab vocab.json --merges merges.txt --out-dir out/
+#
+# One process per GPU.  Rank 0 reads + converts the checkpoint ONCE and hands the four state dicts (CLIP, VAE
+# encoder/decoder, UNet) to every rank in one flat buffer per model over RCCL (the "trivial broadcast" north_star
+# names); each rank then runs the reference-compatible pipeline.generate() (sd/pipeline.py:13-262, latent batch 1 per
+# call: :146) on prompts i = rank, rank + N, ...; rank 0 gathers the uint8 images.  No collective inside the loop.
+# =====================================================================================================================
+
+def model_manifests() -> "OrderedDict[str, Dict[str, Tuple[int, ...]]]":
+    from . import arch
+    return OrderedDict([("clip", arch.clip_manifest()), ("encoder", arch.vae_encoder_manifest()[0]),
+                        ("decoder", arch.vae_decoder_manifest()[0]), ("diffusion", arch.diffusion_manifest())])
+
+
+def broadcast_state_dicts(state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]], manifests, device, src: int = 0,
+                          dtype=torch.float32, group=None) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
+    """Rank ``src`` passes its state dicts ({model: {key: tensor}}, any device); every rank gets views into ONE flat
+    ``dtype`` buffer per model on ``device``.  fp32 keeps every rank bit-identical to a single-GPU load (4.3 GB in
+    all: well under a second over xGMI); fp16 halves it at the cost of rounding the norm/bias vectors too."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    out = {}
+    for name, man in manifests.items():
+        flat = torch.empty(flat_size(man), dtype=dtype, device=device)
+        if rank == src:
+            if state_dicts is None or name not in state_dicts:
+                raise ValueError(f"rank {src} has no state dict for '{name}'")
+            pack_flat(state_dicts[name], man, flat)
+        broadcast_weights(flat, src=src, group=group)
+        out[name] = views_from_flat(flat, man)
+    return out
+
+
+def gather_image_lists(mine: List[torch.Tensor], n_total: int, shape, device=None, dst: int = 0, group=None
+                       ) -> Optional[List[torch.Tensor]]:
+    """Ranks hold the images of prompts rank, rank + N, ... (possibly one fewer on the higher ranks); ``dst`` gets
+    the full list in prompt order.  One gather per round of N prompts."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(mine)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rounds = (n_total + world - 1) // world
+    out: List[torch.Tensor] = []
+    for r in range(rounds):
+        img = mine[r] if r < len(mine) else torch.zeros(shape, dtype=torch.uint8)
+        if device is not None:
+            img = img.to(device)
+        got = gather_images(img.contiguous(), dst=dst, group=group)
+        if rank == dst:
+            out.extend(g.cpu() for i, g in enumerate(got) if r * world + i < n_total)
+    return out if rank == dst else None
+
+
+def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, device, *, seed_base: int = 0,
+                uncond_prompt: str = "", n_inference_steps: int = 50, cfg_scale: float = 7.5, height: int = 512,
+                width: int = 512, input_images: Optional[Sequence] = None, strength: float = 0.8, group=None,
+                gather_device=None, generate=None):
+    """Shard ``prompts`` over the ranks of the initialised process group (prompt i -> rank i mod N, seed =
+    seed_base + i), run generate() per prompt, gather on rank 0.  Returns (images or None, stats)."""
+    import time
+
+    import torch.distributed as dist
+    if generate is None:
+        from .pipeline import generate
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    todo = shard_prompts(list(enumerate(prompts)), rank, world)
+    mine: List[torch.Tensor] = []
+    per_image = []
+    if dist.is_initialized():
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    for i, prompt in todo:
+        t1 = time.perf_counter()
+        img = generate(prompt=prompt, uncond_prompt=uncond_prompt,
+                       input_image=None if input_images is None else input_images[i], strength=strength, do_cfg=True,
+                       cfg_scale=cfg_scale, sampler_name="ddpm", n_inference_steps=n_inference_steps, models=models,
+                       seed=seed_base + i, device=device, idle_device=None, tokenizer=tokenizer, height=height,
+                       width=width)
+        mine.append(torch.from_numpy(img))
+        per_image.append(time.perf_counter() - t1)
+    if torch.cuda.is_available() and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    elapsed = max_over_ranks(time.perf_counter() - t0, device=gather_device, group=group)
+    images = gather_image_lists(mine, len(prompts), (height, width, 3), device=gather_device, group=group)
+    stats = {"n_prompts": len(prompts), "world": world, "elapsed_s": elapsed,
+             "images_per_s": len(prompts) / elapsed if elapsed > 0 else 0.0,
+             "rank0_s_per_image": per_image}
+    return images, stats
+
+
+def _main(argv=None) -> int:
+    import argparse
+    import json
+    import os
+
+    ap = argparse.ArgumentParser(prog="python -m pytorch_stable_diffusion_amd.replicas",
+                                 description="prompt-parallel generate() over the GPUs of one node (one process per GPU)")
+    ap.add_argument("--prompts-file", required=True, help="one prompt per line")
+    ap.add_argument("--ckpt", help="standard SD-v1.x checkpoint (.ckpt); read and converted on rank 0 only")
+    ap.add_argument("--synthetic", action="store_true", help="name-keyed synthetic weights instead of a checkpoint")
+    ap.add_argument("--vocab", help="CLIP vocab.json")
+    ap.add_argument("--merges", help="CLIP merges.txt")
+    ap.add_argument("--stub-tokenizer", action="store_true", help="hash tokenizer (no vocab files offline)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--cfg-scale", type=float, default=7.5)
+    ap.add_argument("--seed-base", type=int, default=0)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--out-dir", default=None)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs")
+    args = ap.parse_args(argv)
+    if bool(args.ckpt) == bool(args.synthetic):
+        ap.error("give exactly one of --ckpt / --synthetic")
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("replicas: needs GPUs (the HIP path has no CPU fallback)")
+    # rendezvous first, on this rank's own device; nothing below re-execs the process
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+
+    with open(args.prompts_file) as f:
+        prompts = [ln.rstrip("\n") for ln in f if ln.strip()]
+    if not prompts:
+        raise SystemExit("replicas: empty prompts file")
+    if args.stub_tokenizer:
+        import zlib
+
+        class _Tok:      # duck-typed batch_encode_plus (sd/pipeline.py:109)
+            def batch_encode_plus(self, texts, padding=None, max_length=77):
+                rows = []
+                for t in texts:
+                    ids = [49406] + [320 + zlib.crc32(w.encode()) % 40000 for w in t.split()][: max_length - 2] + [49407]
+                    rows.append(ids + [49407] * (max_length - len(ids)))
+                return type("Enc", (), {"input_ids": rows})()
+        tokenizer = _Tok()
+    else:
+        if not (args.vocab and args.merges):
+            ap.error("--vocab and --merges are required unless --stub-tokenizer")
+        from .tokenizer import CLIPTokenizer
+        tokenizer = CLIPTokenizer(args.vocab, merges_file=args.merges)
+
+    sds = None
+    if rank == 0:                                   # the checkpoint is read and converted exactly once
+        from . import model_converter, model_loader
+        sds = (model_loader.synthetic_state_dicts() if args.synthetic
+               else model_converter.load_from_standard_weights(args.ckpt, "cpu"))
+    state = broadcast_state_dicts(sds, model_manifests(), dev)
+    del sds
+    from . import model_loader
+    models = model_loader.preload_models_from_state_dicts(state, dev)
+
+    images, stats = run_prompts(prompts, models, tokenizer, dev, seed_base=args.seed_base, n_inference_steps=args.steps,
+                                cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=dev)
+    if rank == 0:
+        if args.out_dir:
+            from PIL import Image
+            os.makedirs(args.out_dir, exist_ok=True)
+            for i, im in enumerate(images):
+                Image.fromarray(im.numpy()).save(os.path.join(args.out_dir, f"image_{i:04d}.png"))
+        print(json.dumps({"metric": "images_per_s", "value": round(stats["images_per_s"], 4), "n_gpus": world,
+                          "n_prompts": len(prompts), "steps": args.steps, "elapsed_s": round(stats["elapsed_s"], 3)}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(_main())

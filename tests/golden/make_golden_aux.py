@@ -42,6 +42,12 @@ def main():
     img = seeded((1, 3, 64, 64), 302).clamp(-1, 1)
     noise = seeded((1, 4, 8, 8), 303)
     out["enc_out"] = e(img.clone(), noise.clone())
+    # the sizes generate() runs at (BASELINE configs 2/3): decoder on 64x64 latents -> 512x512 image (kept 4x
+    # subsampled: 3x128x128), encoder on a 512x512 image -> 4x64x64 latents
+    lat64 = seeded((1, 4, 64, 64), 305) * 0.18215 * 3
+    out["dec64_out_sub4"] = d(lat64.clone())[:, :, ::4, ::4].contiguous()
+    img512 = seeded((1, 3, 512, 512), 306).clamp(-1, 1)
+    out["enc512_out"] = e(img512.clone(), seeded((1, 4, 64, 64), 307))
     np.savez(os.path.join(HERE, "aux.npz"), **{k: v.numpy() for k, v in out.items()})
     print({k: tuple(v.shape) for k, v in out.items()})
 

@@ -43,3 +43,21 @@ def rel_l2(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def inverse_checkpoint(state_dicts, plan):
+    """Route converted state dicts ({'clip','encoder','decoder','diffusion'}) BACKWARDS through the converter's plan
+    into the source layout of a standard SD-v1.x checkpoint: 'copy' -> the tensor itself (a '+reshape' rule's source
+    is the 1x1-conv form (O, I, 1, 1), sd/model_converter.py:1026-1030), 'cat' -> equal row chunks in source order
+    (q | k | v, sd/model_converter.py:1009).  Returns the checkpoint's ``state_dict``."""
+    ckpt = {}
+    for model, rules in plan.items():
+        for dst, rule in rules.items():
+            t = state_dicts[model][dst]
+            parts = [t] if rule["op"].startswith("copy") else list(t.chunk(len(rule["src"]), 0))
+            for k, p in zip(rule["src"], parts):
+                if "shape" in rule:
+                    p = p.reshape(p.shape[0], p.shape[1], 1, 1)
+                assert k not in ckpt, k
+                ckpt[k] = p.contiguous()
+    return ckpt

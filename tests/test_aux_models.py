@@ -1,37 +1,39 @@
-"""Interim CLIP / VAE modules vs golden vectors from the imported reference,
-on CPU (torch ops).  Pins the quirks Q3/Q4 and the in-place latent scaling."""
-import numpy as np
+"""CLIP / VAE oracle (oracle/aux_ref.py) vs golden vectors from the imported reference, on CPU.
+Pins the quirks Q3/Q4 and the in-place latent scaling; the product classes are native-only (no CPU path)."""
+import pytest
 import torch
 
+from oracle import aux_ref
 from pytorch_stable_diffusion_amd import model_loader
 from pytorch_stable_diffusion_amd.clip import CLIP
 from pytorch_stable_diffusion_amd.vae import VAE_Decoder, VAE_Encoder
 from tests import helpers as H
 
 
-def test_clip_vae_match_reference():
+def test_clip_vae_oracle_matches_reference():
     g = H.load_npz("aux.npz")
     sds = model_loader.synthetic_state_dicts(("clip", "encoder", "decoder"))
-    c = CLIP(backend="torch")
-    c.load_state_dict(sds["clip"], strict=True)
-    out = c(torch.from_numpy(g["clip_tokens"]))
+    out = aux_ref.clip_forward(sds["clip"], torch.from_numpy(g["clip_tokens"]))
     assert (out - torch.from_numpy(g["clip_out"])).abs().max().item() < 2e-5
-    d = VAE_Decoder(backend="torch")
-    d.load_state_dict(sds["decoder"], strict=True)
     lat = H.seeded((1, 4, 8, 8), 301) * 0.18215 * 3
     lat_in = lat.clone()
-    img = d(lat_in)
+    img = aux_ref.vae_decode(sds["decoder"], lat_in)
     assert (img - torch.from_numpy(g["dec_out"])).abs().max().item() < 5e-5
     assert abs(float((lat_in / lat).mean()) - float(g["dec_inplace_ratio"])) < 1e-5     # in-place /= 0.18215
-    e = VAE_Encoder(backend="torch")
-    e.load_state_dict(sds["encoder"], strict=True)
     x = H.seeded((1, 3, 64, 64), 302).clamp(-1, 1)
-    z = e(x, H.seeded((1, 4, 8, 8), 303))
+    z = aux_ref.vae_encode(sds["encoder"], x, H.seeded((1, 4, 8, 8), 303))
     assert (z - torch.from_numpy(g["enc_out"])).abs().max().item() < 5e-5
 
 
 def test_strict_loading_errors():
-    import pytest
     d = VAE_Decoder()
     with pytest.raises(RuntimeError):
         d.load_state_dict({"0.weight": torch.zeros(4, 4, 1, 1)}, strict=True)
+
+
+@pytest.mark.parametrize("cls", [CLIP, VAE_Decoder, VAE_Encoder])
+def test_no_cpu_fallback(cls):
+    """The product models are native-only: on a CPU device they refuse to run instead of falling back."""
+    m = cls()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.handle()

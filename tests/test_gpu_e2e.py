@@ -1,6 +1,7 @@
 """End-to-end drop-in check (-m gpu): this repo's pipeline.generate() on the GPU (native CLIP, UNet loop,
 VAE encoder/decoder: every model on the HIP library) against the image the reference's own generate() produced on the CPU with the
-same synthetic weights, stub tokenizer, seed and prompt (tests/golden/e2e.npz).
+same synthetic weights, stub tokenizer, seed and prompt (tests/golden/e2e.npz: 20-step txt2img / 8-step img2img; tests/golden/e2e50.npz: the 50-step configs as BASELINE
+states them and a 3-step 768x768 run).
 Stated tolerance (north_star): pixel MAE < 1e-3 on the [0,1] float image; uint8 images may differ by a few LSB."""
 import numpy as np
 import pytest
@@ -38,16 +39,42 @@ def models():
     return m
 
 
-def _check(name, img, float_img, g):
+U8_MAX = 3          # measured 1-2 LSB (truncating cast of values that differ by < 1e-3 of the range)
+
+
+def _check(name, img, float_img, g, drift=None):
     ref_u8 = g[f"{name}_u8"]
     ref_f = torch.from_numpy(g[f"{name}_float"])
     assert img.shape == ref_u8.shape == (512, 512, 3) and img.dtype == np.uint8
     got_f = float_img[0, :, ::4, ::4].cpu()
     mae = ((got_f - ref_f).abs().mean() / 2.0).item()          # decoder output is in [-1,1] -> /2 = [0,1] scale
     du8 = np.abs(img.astype(np.int32) - ref_u8.astype(np.int32))
-    G.log_metric(test="e2e", name=name, pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()))
-    assert mae < PIXEL_MAE, f"{name}: pixel MAE {mae:.2e}"
-    assert du8.max() <= 8, f"{name}: uint8 max diff {du8.max()}"
+    G.log_metric(test="e2e", name=name, pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()), drift=drift)
+    assert mae < PIXEL_MAE, f"{name}: pixel MAE {mae:.2e} (latent drift every 5th step: {drift})"
+    assert du8.max() <= U8_MAX, f"{name}: uint8 max diff {du8.max()}"
+
+
+class StepTap:
+    """Records the latents entering every 5th fused step of the native loop (drift localisation against the
+    reference's per-step latents in e2e50.npz)."""
+
+    def __init__(self, model):
+        self.model, self.seen, self._orig = model, [], model.step
+
+    def __enter__(self):
+        def step(lat, i, *a, **k):
+            if i % 5 == 0:
+                self.seen.append(lat.detach().cpu().clone())
+            return self._orig(lat, i, *a, **k)
+        self.model.step = step
+        return self
+
+    def __exit__(self, *exc):
+        del self.model.step            # back to the class attribute
+
+    def drift(self, ref_every5):
+        ref = torch.from_numpy(ref_every5)
+        return [round(H.rel_l2(a, ref[j:j + 1]), 6) for j, a in enumerate(self.seen)]
 
 
 def test_txt2img_matches_reference_generate(models):
@@ -80,22 +107,58 @@ def test_generate_argument_errors(models):
         pipeline.generate("a", "", models={}, device=DEV, tokenizer=StubTokenizer())
 
 
-def test_768_generate_runs(models):
-    """BASELINE config 5 shape (96x96 latents): the loop and VAE run and return a 768x768 image."""
+def test_txt2img_50_steps_matches_reference_generate(models):
+    """BASELINE config 2 as stated: 512x512, 50 DDPM steps, CFG 7.5 (seed 42) vs the reference's own 50-step
+    generate() on the CPU (tests/golden/e2e50.npz).  north_star tolerance: pixel MAE < 1e-3."""
     from pytorch_stable_diffusion_amd import pipeline
-    img = pipeline.generate(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, n_inference_steps=2,
+    g = H.load_npz("e2e50.npz")
+    with StepTap(models["diffusion"]) as tap:
+        img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True,
+                                cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=50, models=models, seed=42,
+                                device=DEV, idle_device=None, tokenizer=StubTokenizer())
+    _check("txt50", img, models["decoder"].last, g, tap.drift(g["txt50_lat_every5"]))
+
+
+def test_img2img_50_steps_strength08_matches_reference_generate(models):
+    """BASELINE config 3 as stated: img2img from dog.jpg, strength 0.8 on the 50-step schedule = 40 steps from
+    t = 780 (sd/ddpm.py:90-99), seed 7, vs the reference's own run."""
+    from PIL import Image
+    from pytorch_stable_diffusion_amd import pipeline
+    g = H.load_npz("e2e50.npz")
+    dog = Image.fromarray(H.load_npz("e2e.npz")["dog_u8"])
+    with StepTap(models["diffusion"]) as tap:
+        img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=dog, strength=0.8, do_cfg=True,
+                                cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=50, models=models, seed=7,
+                                device=DEV, idle_device=None, tokenizer=StubTokenizer())
+    assert len(tap.seen) == 8                                    # 40 steps ran
+    _check("img50", img, models["decoder"].last, g, tap.drift(g["img50_lat_every5"]))
+
+
+def test_768_generate_matches_reference(models):
+    """BASELINE config 5 shape (768x768 = 4x96x96 latents, S = 9216 self-attention): 3 steps, seed 1, against the
+    reference's generate() run with its module constants set to 768 (tests/golden/make_golden_e2e50.py)."""
+    from pytorch_stable_diffusion_amd import pipeline
+    g = H.load_npz("e2e50.npz")
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, n_inference_steps=3,
                             models=models, seed=1, device=DEV, tokenizer=StubTokenizer(), height=768, width=768)
-    assert img.shape == (768, 768, 3)
+    assert img.shape == (768, 768, 3) and img.dtype == np.uint8
+    got_f = models["decoder"].last[0, :, ::4, ::4].cpu()
+    ref_f = torch.from_numpy(g["t768_float"])
+    mae = ((got_f - ref_f).abs().mean() / 2.0).item()
+    du8 = np.abs(img[::2, ::2].astype(np.int32) - g["t768_u8"].astype(np.int32))
+    G.log_metric(test="e2e", name="t768", pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()))
+    assert mae < PIXEL_MAE, f"768x768: pixel MAE {mae:.2e}"
+    assert du8.max() <= U8_MAX, f"768x768: uint8 max diff {du8.max()}"
 
 
 def test_native_vae_decoder_vs_reference():
-    """Native HIP VAE decoder (csrc/vae.hip) vs the reference decoder's golden output (8x8 latents) and vs
-    the torch-op restatement at 64x64 latents (the size generate() uses), incl. quirks Q3/Q4."""
+    """Native HIP VAE decoder (csrc/vae.hip) vs the reference decoder's golden outputs at 8x8 latents and at 64x64
+    latents (the size generate() uses; image kept 4x subsampled), incl. quirks Q3/Q4."""
     from pytorch_stable_diffusion_amd import model_loader
     from pytorch_stable_diffusion_amd.vae import VAE_Decoder
     g = H.load_npz("aux.npz")
     sd = model_loader.synthetic_state_dicts(("decoder",))["decoder"]
-    nat = VAE_Decoder(backend="native")
+    nat = VAE_Decoder()
     nat.load_state_dict(sd, strict=True)
     nat.to(DEV)
     lat = (H.seeded((1, 4, 8, 8), 301) * 0.18215 * 3).to(DEV)
@@ -104,16 +167,13 @@ def test_native_vae_decoder_vs_reference():
     rel = H.rel_l2(img, ref)
     G.log_metric(test="vae_native", size=8, rel_l2=rel, max_abs=(img - ref).abs().max().item())
     assert rel < 5e-3, f"8x8: rel L2 {rel:.2e}"
-    tor = VAE_Decoder(backend="torch")
-    tor.load_state_dict(sd, strict=True)
-    tor.to(DEV)
     lat64 = (H.seeded((1, 4, 64, 64), 305) * 0.18215 * 3).to(DEV)
-    a = nat(lat64.clone())
-    b = tor(lat64.clone())
-    rel = H.rel_l2(a.cpu(), b.cpu())
+    a = nat(lat64.clone())[:, :, ::4, ::4].cpu()
+    b = torch.from_numpy(g["dec64_out_sub4"])
+    rel = H.rel_l2(a, b)
     mae = ((a - b).abs().mean() / 2).item()
     G.log_metric(test="vae_native", size=64, rel_l2=rel, pixel_mae=mae, launches=nat.handle().last_launch_count)
-    assert rel < 5e-3 and mae < 1e-3, f"64x64: rel L2 {rel:.2e}, pixel MAE {mae:.2e}"
+    assert rel < 5e-3 and mae < 6e-4, f"64x64: rel L2 {rel:.2e}, pixel MAE {mae:.2e}"
 
 
 def test_native_clip_vs_reference():
@@ -123,7 +183,7 @@ def test_native_clip_vs_reference():
     from pytorch_stable_diffusion_amd.clip import CLIP
     g = H.load_npz("aux.npz")
     sd = model_loader.synthetic_state_dicts(("clip",))["clip"]
-    c = CLIP(backend="native")
+    c = CLIP()
     c.load_state_dict(sd, strict=True)
     c.to(DEV)
     tokens = torch.from_numpy(g["clip_tokens"]).to(DEV)
@@ -131,19 +191,19 @@ def test_native_clip_vs_reference():
     ref = torch.from_numpy(g["clip_out"])
     rel = H.rel_l2(out, ref)
     G.log_metric(test="clip_native", rel_l2=rel, max_abs=(out - ref).abs().max().item(), launches=c.handle().last_launch_count)
-    assert rel < 3e-3, f"rel L2 {rel:.2e}"
+    assert rel < 2e-3, f"rel L2 {rel:.2e}"          # measured 6.9e-4
     one = c(tokens[:1]).cpu()                 # batch 1 == row 0 of the batch-2 call
     assert H.rel_l2(one, out[:1]) < 1e-3
 
 
 def test_native_vae_encoder_vs_reference():
-    """Native HIP VAE encoder (csrc/vae.hip) vs the reference encoder's golden latents (64x64 image) and vs the
-    torch-op restatement at 512x512 (asymmetric stride-2 padding, clamp/exp/sqrt reparameterisation, 0.18215)."""
+    """Native HIP VAE encoder (csrc/vae.hip) vs the reference encoder's golden latents for a 64x64 and a 512x512
+    image (asymmetric stride-2 padding, clamp/exp/sqrt reparameterisation, 0.18215)."""
     from pytorch_stable_diffusion_amd import model_loader
     from pytorch_stable_diffusion_amd.vae import VAE_Encoder
     g = H.load_npz("aux.npz")
     sd = model_loader.synthetic_state_dicts(("encoder",))["encoder"]
-    nat = VAE_Encoder(backend="native")
+    nat = VAE_Encoder()
     nat.load_state_dict(sd, strict=True)
     nat.to(DEV)
     x = H.seeded((1, 3, 64, 64), 302).clamp(-1, 1).to(DEV)
@@ -151,13 +211,9 @@ def test_native_vae_encoder_vs_reference():
     ref = torch.from_numpy(g["enc_out"])
     rel = H.rel_l2(z, ref)
     G.log_metric(test="vae_enc_native", size=64, rel_l2=rel, max_abs=(z - ref).abs().max().item())
-    assert rel < 5e-3, f"64x64: rel L2 {rel:.2e}"
-    tor = VAE_Encoder(backend="torch")
-    tor.load_state_dict(sd, strict=True)
-    tor.to(DEV)
+    assert rel < 1.2e-3, f"64x64: rel L2 {rel:.2e}"          # measured 3.6e-4
     x2 = H.seeded((1, 3, 512, 512), 306).clamp(-1, 1).to(DEV)
     n2 = H.seeded((1, 4, 64, 64), 307).to(DEV)
-    a, b = nat(x2, n2), tor(x2.clone(), n2)
-    rel = H.rel_l2(a.cpu(), b.cpu())
+    rel = H.rel_l2(nat(x2, n2).cpu(), torch.from_numpy(g["enc512_out"]))
     G.log_metric(test="vae_enc_native", size=512, rel_l2=rel)
-    assert rel < 5e-3, f"512x512: rel L2 {rel:.2e}"
+    assert rel < 1.2e-3, f"512x512: rel L2 {rel:.2e}"

@@ -192,7 +192,7 @@ def test_flash_attention(d, Sq, Skv):
     out = G.attention(q.to(DEV), k.to(DEV), vt.to(DEV), B, Hh, d, Sq, Skv)
     err = (out.cpu().double() - ref).abs().max().item()
     G.log_metric(test="attention", d=d, Sq=Sq, Skv=Skv, max_abs_err=err)
-    assert err < 4e-3, f"d={d} Sq={Sq} Skv={Skv}: max abs err {err}"
+    assert err < 2e-3, f"d={d} Sq={Sq} Skv={Skv}: max abs err {err}"       # measured 1.4e-4 .. 8.1e-4
 
 
 def test_flash_attention_large_logits():
@@ -208,7 +208,8 @@ def test_flash_attention_large_logits():
     vt = v.view(B, S, Hh * d).permute(0, 2, 1).contiguous().view(B * Hh * d, S)
     out = G.attention(q.to(DEV), k.to(DEV), vt.to(DEV), B, Hh, d, S, S)
     err = (out.cpu().double() - ref).abs().max().item()
-    assert err < 4e-3, f"max abs err {err}"
+    G.log_metric(test="attention_spike", max_abs_err=err)
+    assert err < 2.5e-3, f"max abs err {err}"
 
 
 @pytest.mark.parametrize("C0,C1,P,in_f32,silu,eps", [(320, 0, 64, True, True, 1e-5), (640, 320, 256, False, True, 1e-5),
@@ -233,7 +234,26 @@ def test_groupnorm(C0, C1, P, in_f32, silu, eps):
     y = G.groupnorm(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), eps, silu)
     err = (y.cpu().double() - ref).abs().max().item()
     G.log_metric(test="groupnorm", C0=C0, C1=C1, P=P, max_abs_err=err)
-    assert err < 6e-3, f"max abs err {err}"
+    assert err < 4e-3, f"max abs err {err}"        # measured 1.95e-3 = half an fp16 ulp of the largest outputs (|y| ~ 4)
+
+
+@pytest.mark.parametrize("P,offset", [(4096, 30.0), (1024, -30.0), (4096, 100.0), (64, 30.0)])
+def test_groupnorm_large_mean(P, offset):
+    """|mean| >= 30 sigma in every group: the two-launch path computes the variance as E[x^2] - E[x]^2 in fp32 from
+    fixed-order partial sums (norm.hip gn_apply_kernel), whose relative error grows like eps_fp32 * (mean/sigma)^2
+    = 5e-5 at 30 sigma, 6e-4 at 100 sigma -- both far below the fp16 rounding of the output.  (P = 64 takes the
+    single-launch kernel, which is exact two-pass.)  Inputs are the fp32 stream, as in the UNet."""
+    B, C0 = 2, 320
+    Hh = int(math.isqrt(P))
+    g = torch.Generator().manual_seed(P)
+    x0 = torch.randn((B, Hh, Hh, C0), generator=g) + offset
+    gamma = 1 + 0.1 * torch.randn((C0,), generator=g)
+    beta = 0.1 * torch.randn((C0,), generator=g)
+    ref = F.silu(F.group_norm(x0.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 3, 1)
+    y = G.groupnorm(x0.to(DEV), None, gamma.to(DEV), beta.to(DEV), 1e-5, True)
+    err = (y.cpu().double() - ref).abs().max().item()
+    G.log_metric(test="groupnorm_large_mean", P=P, offset=offset, max_abs_err=err)
+    assert err < (4e-3 if abs(offset) <= 30 else 8e-3), f"max abs err {err}"
 
 
 @pytest.mark.parametrize("M,Cc,in_f32", [(128, 320, True), (300, 640, False), (64, 1280, True)])

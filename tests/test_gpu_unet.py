@@ -10,11 +10,12 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# fp16 operands / fp32 accumulation: a single block lands around 1e-3 relative L2 against the fp32
-# reference; the stated bound is 4e-3 per block and 6e-3 for the whole UNet (SURVEY 8c measured
-# 1.5e-3 for a torch-CPU fp16 UNet).
-BLOCK_REL_L2 = 4e-3
-UNET_REL_L2 = 6e-3
+# fp16 operands / fp32 accumulation.  Bounds are <= 3x what the path measures on MI355X (round 1: blocks
+# 1.5e-4 .. 3.5e-4 with the fp32 stream, 3.3e-4 .. 4.2e-4 with the fp16 stream; whole UNet 9.2e-4 .. 9.7e-4;
+# 20-step loop 9.0e-4), so a numerical regression trips them.  (a torch-CPU fp16 UNet sits at 1.5e-3.)
+BLOCK_REL_L2 = {"stream_f32": 9e-4, "stream_f16": 1.2e-3}
+UNET_REL_L2 = 2.5e-3
+LOOP20_REL_L2 = 2.5e-3
 
 
 def _nhwc(x):
@@ -62,7 +63,7 @@ def test_block_vs_golden(block_handle, name):
     rel = H.rel_l2(got, ref)
     mx = (got - ref).abs().max().item()
     G.log_metric(test="block", name=name, mode=mode, rel_l2=rel, max_abs=mx, launches=h.last_launch_count)
-    assert rel < BLOCK_REL_L2, f"{name} [{mode}]: rel L2 {rel:.2e}, max abs {mx:.2e}"
+    assert rel < BLOCK_REL_L2[mode], f"{name} [{mode}]: rel L2 {rel:.2e}, max abs {mx:.2e}"
 
 
 def test_block_concat_input(block_handle):
@@ -75,7 +76,7 @@ def test_block_concat_input(block_handle):
     xa, xb = _nhwc(x[:, :1280]).to(DEV), _nhwc(x[:, 1280:]).to(DEV)
     out = h.run_block(m["prefix"], 0, xa, x1=xb, time=time, out_shape=(2, 8, 8, 1280))
     rel = H.rel_l2(_nchw(out.cpu()), ref)
-    assert rel < BLOCK_REL_L2, f"rel L2 {rel:.2e}"
+    assert rel < BLOCK_REL_L2[mode], f"rel L2 {rel:.2e}"
 
 
 @pytest.fixture(scope="module")
@@ -153,7 +154,7 @@ def test_loop_20_steps_vs_reference_generate(full_model):
     rel = H.rel_l2(final, ref)
     mae = (final - ref).abs().mean().item()
     G.log_metric(test="loop20", rel_l2=rel, mae=mae, drift=drift)
-    assert rel < 2e-2, f"final latents rel L2 {rel:.2e} (per-step drift {drift})"
+    assert rel < LOOP20_REL_L2, f"final latents rel L2 {rel:.2e} (per-step drift {drift})"
 
 
 def test_attention_blocks_with_separate_layernorm_kernel():
@@ -168,3 +169,52 @@ def test_attention_blocks_with_separate_layernorm_kernel():
                         "test_block_vs_golden and attn"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_no_tune_flag_parity():
+    """SDMI_FLAG_NO_TUNE: heuristic tile choice (gemm.hip pick_cfg), no timing runs -- same parity as the tuned plans."""
+    from pytorch_stable_diffusion_amd import _native as N
+    meta = H.blocks_meta()["blocks"]
+    names = ["res_320_640", "attn_8_80", "res_2560_1280", "up_640"]
+    state = {}
+    for n in names:
+        for k, v in H.block_weights(meta[n]["prefix"]).items():
+            state[k] = v.to(DEV)
+    h = N.UNetHandle(state, N.FLAG_PARTIAL | N.FLAG_STREAM_F32 | N.FLAG_NO_TUNE)
+    h.set_context(H.seeded((2, 77, 768), 7).to(DEV))
+    for n in names:
+        m = meta[n]
+        ref = torch.from_numpy(H.load_npz("blocks.npz")[n])
+        kind = {"res": 0, "attn": 1, "up": 2}[m["kind"]]
+        time = H.seeded((1, 1280), 8).to(DEV) if kind == 0 else None
+        x = H.seeded(tuple(m["ishape"]), m["seed"])
+        out = h.run_block(m["prefix"], kind, _nhwc(x).to(DEV), time=time,
+                          out_shape=(ref.shape[0], ref.shape[2], ref.shape[3], ref.shape[1]))
+        rel = H.rel_l2(_nchw(out.cpu()), ref)
+        G.log_metric(test="block_no_tune", name=n, rel_l2=rel)
+        assert rel < BLOCK_REL_L2["stream_f32"], f"{n}: rel L2 {rel:.2e}"
+    assert h.tuned_shapes == 0
+    h.close()
+
+
+def test_plan_cache_makes_second_process_deterministic_and_tune_free(tmp_path):
+    """Tuner plans persist (engine.h PlanStore): with an empty cache the first process times its shapes and appends
+    them to plans-<library hash>.txt; the second and third processes read them back, time nothing, and -- running the
+    same plans, hence the same split-K summation order -- produce bit-identical outputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDMI_PLAN_CACHE_DIR=str(tmp_path), SDMI_PLAN_FILE=os.devnull, PYTHONPATH=root)
+    runs = []
+    for _ in range(3):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_plan_child.py")], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        tuned, sha = r.stdout.split()[-2:]
+        runs.append((int(tuned), sha))
+    assert runs[0][0] > 0, runs
+    assert runs[1][0] == 0 and runs[2][0] == 0, runs
+    assert runs[1][1] == runs[2][1], runs
+    files = [f for f in os.listdir(tmp_path) if f.startswith("plans-")]
+    assert len(files) == 1

@@ -62,3 +62,45 @@ def test_convert_fake_checkpoint_shapes_and_values():
     r = full["diffusion"][k]
     t = torch.cat([ckpt[s] for s in r["src"]], 0)
     assert t[0, 0] < t[320, 0] < t[640, 0]          # rows ordered q | k | v (sd/model_converter.py:1009)
+
+
+def test_load_from_standard_weights_executes_and_roundtrips(tmp_path):
+    """SURVEY row f2, executed: a pickled ``{"state_dict": ...}`` checkpoint (every source key of the plan, the
+    synthetic weights routed backwards through it) goes through the product's ``load_from_standard_weights``
+    (torch.load + convert_state_dict: copy / cat / reshape, sd/model_converter.py:3-8,1009-1030) and must come back
+    tensor-for-tensor, with the manifests' shapes, ready for the strict loads of sd/model_loader.py:26-42."""
+    from pytorch_stable_diffusion_amd import model_loader
+    plan = model_converter.conversion_plan()
+    sds = model_loader.synthetic_state_dicts()
+    ckpt = H.inverse_checkpoint(sds, plan)
+    assert len(ckpt) == sum(len(r["src"]) for m in plan.values() for r in m.values())
+    path = os.path.join(tmp_path, "fake-v1-5.ckpt")
+    torch.save({"state_dict": ckpt, "global_step": 0}, path)
+    del ckpt
+    conv = model_converter.load_from_standard_weights(path, "cpu")
+    manifests = {"diffusion": arch.diffusion_manifest(), "clip": arch.clip_manifest(),
+                 "encoder": arch.vae_encoder_manifest()[0], "decoder": arch.vae_decoder_manifest()[0]}
+    assert set(conv) == set(sds)
+    for model, sd in sds.items():
+        assert list(conv[model].keys()) == list(plan[model].keys())
+        for k, v in sd.items():
+            got = conv[model][k]
+            assert tuple(got.shape) == tuple(manifests[model][k]), (model, k, got.shape)
+            assert torch.equal(got, v), (model, k)
+    # the strict loads the reference's loader performs (device-independent part)
+    from pytorch_stable_diffusion_amd.clip import CLIP
+    from pytorch_stable_diffusion_amd.diffusion import Diffusion
+    from pytorch_stable_diffusion_amd.vae import VAE_Decoder, VAE_Encoder
+    for cls, name in ((CLIP, "clip"), (VAE_Encoder, "encoder"), (VAE_Decoder, "decoder"), (Diffusion, "diffusion")):
+        cls().load_state_dict(conv[name], strict=True)
+    bad = dict(conv["clip"])
+    bad.pop("layernorm.weight")
+    import pytest
+    with pytest.raises(RuntimeError):
+        CLIP().load_state_dict(bad, strict=True)
+
+
+def test_convert_state_dict_missing_source_key_raises():
+    import pytest
+    with pytest.raises(KeyError):
+        model_converter.convert_state_dict({"model.diffusion_model.time_embed.0.weight": torch.zeros(1280, 320)})

@@ -66,3 +66,98 @@ def test_flat_layout_alignment():
     assert all(off % 8 == 0 for off, _ in lay.values())
     assert replicas.flat_size(man) >= arch.n_params(man)
     assert replicas.shard_prompts(["a", "b", "c"], 0, 1) == ["a", "b", "c"]
+
+
+# ---- generate()-level launcher (BASELINE config 4) on CPU: world-2 gloo, stub models -------------------------------
+class _Stub:
+    def __init__(self, sd):
+        self.sd = sd
+
+    def to(self, device):
+        return self
+
+
+class _StubClip(_Stub):
+    def __call__(self, tokens):                       # (1,77) -> (1,77,768)
+        return self.sd["emb"][tokens % self.sd["emb"].shape[0]]
+
+
+class _StubUNet(_Stub):
+    def __call__(self, latent, context, time):        # reference convention model(latent, context, time)
+        return self.sd["mix"][0] * latent + self.sd["mix"][1] * context.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.01 * time.mean()
+
+
+class _StubDecoder(_Stub):
+    def __call__(self, latents):                      # (1,4,h,w) -> (1,3,8h,8w)
+        up = torch.nn.functional.interpolate(latents[:, :3], scale_factor=8, mode="nearest")
+        return torch.tanh(up * self.sd["gain"][0])
+
+
+_STUB_MANIFESTS = {"clip": {"emb": (101, 768)}, "diffusion": {"mix": (2,)}, "decoder": {"gain": (1,)}}
+_PROMPTS = ["a dog", "a cat on a mat", "two birds", "a red car", "the sea at night"]
+
+
+def _stub_weights():
+    g = torch.Generator().manual_seed(9)
+    return {"clip": {"emb": torch.randn((101, 768), generator=g)}, "diffusion": {"mix": torch.tensor([0.05, 0.3])},
+            "decoder": {"gain": torch.tensor([0.7])}}
+
+
+def _stub_models(sds):
+    return {"clip": _StubClip(sds["clip"]), "diffusion": _StubUNet(sds["diffusion"]), "decoder": _StubDecoder(sds["decoder"])}
+
+
+def _stub_generate(prompt, uncond_prompt=None, models=None, seed=None, tokenizer=None, n_inference_steps=3, height=64,
+                   width=64, cfg_scale=7.5, **_):
+    """Same call surface as pipeline.generate (the product's sampler step is a HIP kernel: no CPU path), reduced to
+    what the launcher depends on: the image is a function of (prompt, seed, every model's weights)."""
+    gen = torch.Generator().manual_seed(seed)
+    ids = lambda t: torch.tensor(tokenizer.batch_encode_plus([t], padding="max_length", max_length=77).input_ids)
+    ctx = torch.cat([models["clip"](ids(prompt)), models["clip"](ids(uncond_prompt))])
+    lat = torch.randn((1, 4, height // 8, width // 8), generator=gen)
+    for t in range(n_inference_steps):
+        c, u = models["diffusion"](lat.repeat(2, 1, 1, 1), ctx, torch.full((1, 320), float(t))).chunk(2)
+        lat = lat - 0.1 * (cfg_scale * (c - u) + u)
+    img = models["decoder"](lat)
+    return ((img.clamp(-1, 1) + 1) * 127.5).permute(0, 2, 3, 1).to(torch.uint8).numpy()[0]
+
+
+def _gen_worker(rank, world, port, q):
+    from tests.stub_tokenizer import StubTokenizer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sds = replicas.broadcast_state_dicts(_stub_weights() if rank == 0 else None, _STUB_MANIFESTS, "cpu")
+        imgs, stats = replicas.run_prompts(_PROMPTS, _stub_models(sds), StubTokenizer(), "cpu", seed_base=100,
+                                           n_inference_steps=3, height=64, width=64, generate=_stub_generate)
+        q.put((rank, None if imgs is None else [i.numpy() for i in imgs], stats["n_prompts"], stats["elapsed_s"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generate_level_launcher_world2_matches_single_process():
+    """run_prompts over two gloo ranks (weights handed out by broadcast_state_dicts, prompts i -> rank i mod 2,
+    seeds seed_base + i, images gathered in prompt order on rank 0) == the same prompts in one process."""
+    from tests.stub_tokenizer import StubTokenizer
+    models = _stub_models(_stub_weights())
+    want = [_stub_generate(prompt=p, uncond_prompt="", models=models, seed=100 + i, tokenizer=StubTokenizer())
+            for i, p in enumerate(_PROMPTS)]
+    assert len({w.tobytes() for w in want}) == len(want)          # prompts/seeds give distinct images
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gen_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][1] is None and res[0][2] == 5
+    assert res[0][3] == res[1][3]                                  # max-over-ranks elapsed agrees
+    got = res[0][1]
+    assert len(got) == 5
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == (64, 64, 3) and (g == w).all(), f"prompt {i}"
