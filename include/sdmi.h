@@ -161,6 +161,10 @@ typedef struct sdmi_gemm_desc {
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_c; float ln_eps;
   int out_t_perm;   /* 1: out_t's key axis in the quad-permuted order sdmi_op_attention reads; 0: natural order */
+  /* GroupNorm(32)(+SiLU) of the A operand fused into a 3x3 stride-1 conv (sd/diffusion.py:173-179,199-205): a0 | a1 are
+   * the RAW activations, gn_partial the statistics sdmi_op_gn_stats wrote ([B][gn_nchunk][32][2] fp32), gn_gamma /
+   * gn_beta the (c0+c1) affine parameters.  Only the "g..." configs accept it (cfg < 0 picks one); NULL: plain conv. */
+  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
@@ -189,6 +193,10 @@ int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1
                       const float* gamma, const float* beta, float eps, int silu, void* y_f16, void* stream);
 int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,
                       void* y_f16, void* stream);
+/* GroupNorm statistics only: per (image, pixel chunk, group) partial {sum, sum of squares} into partial_out
+ * ([B][nchunk][32][2] fp32, nchunk = sdmi_gn_num_chunks(P)); consumed by sdmi_op_gemm's gn_partial. */
+int sdmi_gn_num_chunks(int P);
+int sdmi_op_gn_stats(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, float* partial_out, void* stream);
 
 #ifdef __cplusplus
 }

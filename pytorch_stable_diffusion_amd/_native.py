@@ -33,7 +33,9 @@ class GemmDesc(C.Structure):
                 ("cfg", C.c_int), ("ksplit", C.c_int),
                 ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int),
                 ("rowstat", C.c_void_p), ("ln_stat", C.c_void_p), ("ln_ntn", C.c_int), ("ln_g", C.c_void_p),
-                ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int)]
+                ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int),
+                ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+                ("gn_eps", C.c_float), ("gn_silu", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -81,6 +83,8 @@ _SIGNATURES = {
     "sdmi_op_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "sdmi_gemm_config_dims": (None, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdmi_gn_num_chunks": (C.c_int, [C.c_int]),
+    "sdmi_op_gn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sdmi_op_ln_fold_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -91,6 +91,11 @@ struct GemmArgs {
   float cscale; int cs_hi;
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_C; float ln_eps;
+  // GroupNorm(32) (+SiLU) of the A operand fused into the 3x3 conv (conv3_gn_kernel; sd/diffusion.py:173-179,199-205):
+  // a0 | a1 are the RAW activations; gn_partial = gn_stats_kernel's per-chunk {sum, sum of squares} per group
+  // ([B][gn_nchunk][32][2]), reduced in the conv's prologue; y = silu(x * (rstd gamma) + (beta - mean rstd gamma)) is
+  // applied once per staged halo chunk in LDS, and the 9 taps read the normalised image.  nullptr: plain conv.
+  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
 };
 
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
@@ -135,6 +140,7 @@ struct GnArgs {
 int sdmi_gn_nchunk(int P);
 int sdmi_gn_launches(const GnArgs& a);
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st);
+int sdmi_launch_gn_stats(const GnArgs& a, hipStream_t st);   // statistics only (consumer: conv3_gn_kernel via GemmArgs::gn_partial)
 
 struct LnArgs {
   const void* x; int in_f32;  // [M][C]

@@ -192,6 +192,27 @@ struct Engine {
   bool profiling = false;
   struct ProfRec { hipEvent_t e0, e1; int cls; double flops; };
   std::vector<ProfRec> prof;
+  // optional launch log (SDMI_LAUNCH_LOG=<file>): one line per kernel launch of the last forward, in launch order,
+  // so a rocprofv3 kernel trace / PMC pass can be joined with the shape each kernel ran (tools/join_trace.py)
+  struct LaunchRec { char text[160]; };
+  std::vector<LaunchRec> launch_log;
+  bool logging = getenv("SDMI_LAUNCH_LOG") != nullptr;
+  void log_launch(const char* fmt, ...) {
+    if (!logging) return;
+    LaunchRec r;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(r.text, sizeof(r.text), fmt, ap);
+    va_end(ap);
+    launch_log.push_back(r);
+  }
+  void write_launch_log() {
+    if (!logging) return;
+    FILE* f = fopen(getenv("SDMI_LAUNCH_LOG"), "w");
+    if (!f) return;
+    for (const LaunchRec& r : launch_log) fprintf(f, "%s\n", r.text);
+    fclose(f);
+  }
   void prof_begin(int cls, double flops) {
     if (!profiling) return;
     ProfRec r; r.cls = cls; r.flops = flops;
@@ -405,10 +426,11 @@ struct Engine {
 
   // ---- GEMM with per-shape plan -----------------------------------------------------------------
   // rs != null: ask the epilogue for LayerNorm row statistics of the output (granted when the plan has ksplit == 1)
-  int gemm(GemmArgs a, RowStat* rs = nullptr) {
+  // plan of a GEMM shape: this handle's table, else the plan store (shipped table / per-library cache), else tuned now
+  int plan_of(GemmArgs& a, std::map<ShapeKey, Plan>::iterator* out) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr),
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 1024 * (a.gn_partial != nullptr),
                  a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
@@ -432,6 +454,13 @@ struct Engine {
       }
       it = plans.emplace(key, pl).first;
     }
+    *out = it;
+    return SDMI_OK;
+  }
+
+  int gemm(GemmArgs a, RowStat* rs = nullptr) {
+    std::map<ShapeKey, Plan>::iterator it;
+    TRY(plan_of(a, &it));
     a.ksplit = it->second.ksplit;
     if (rs) {
       static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
@@ -453,6 +482,14 @@ struct Engine {
     TRY(sdmi_launch_gemm(a, it->second.cfg, st));
     prof_end();
     launches += nl;
+    if (logging) {
+      const int cfg = it->second.cfg;
+      const bool halo = cfg >= sdmi_gemm_num_plain_cfgs();
+      log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
+                 a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.ksplit, 2.0 * a.M * a.N * a.K,
+                 2.0 * a.N * a.K, a.out_f32, a.res != nullptr);
+      if (a.ksplit > 1) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
+    }
     return SDMI_OK;
   }
 
@@ -550,8 +587,53 @@ struct Engine {
     TRY(sdmi_launch_groupnorm(g, st));
     prof_end();
     launches += sdmi_gn_launches(g);
+    if (sdmi_gn_launches(g) == 1) log_launch("gn_fused C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu);
+    else { log_launch("gn_stats C=%d P=%d B=%d", C, g.P, g.B); log_launch("gn_apply C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu); }
     return SDMI_OK;
   }
+  // ---- GroupNorm(+SiLU) fused into the following 3x3 conv (conv3_gn_kernel) --------------------------------
+  // gn_fuse (SDMI_GN_FUSE): 0 off, 1 auto (per shape, whichever pipeline's plans are faster), 2 always when a g-config fits
+  int gn_fuse = getenv("SDMI_GN_FUSE") ? atoi(getenv("SDMI_GN_FUSE")) : 1;
+  void set_gn(GemmArgs& a, const NormW& w, float eps, int silu) const {
+    a.gn_partial = gn_partial; a.gn_nchunk = sdmi_gn_nchunk(a.Hs * a.Ws);
+    a.gn_gamma = w.gamma; a.gn_beta = w.beta; a.gn_eps = eps; a.gn_silu = silu;
+  }
+  bool gn_candidate(const GemmArgs& a) const {
+    if (gn_fuse == 0) return false;
+    for (int c = sdmi_gemm_num_plain_cfgs(); c < sdmi_gemm_num_cfgs(); ++c)
+      if (sdmi_gemm_cfg_applicable(a, c)) return true;
+    return false;
+  }
+  // Auto mode: fuse when the fused conv's plan is faster than the best unfused conv plan + the gn_apply launch it
+  // replaces (modelled as 3.5 us + bytes / 2.8 TB/s: measured 8.9 us for C=320 at 64x64, 12.3 us for C=640, 7.1 us for
+  // C=640 at 32x32).  Both argument sets must be complete (the plans may be timed right here).
+  int gn_fuse_wins(GemmArgs fused, GemmArgs unfused, bool in_f32, bool* win) {
+    if (gn_fuse == 2 || !tune) { *win = true; return SDMI_OK; }
+    std::map<ShapeKey, Plan>::iterator pf, pu;
+    TRY(plan_of(fused, &pf));
+    TRY(plan_of(unfused, &pu));
+    const double elems = (double)fused.M * (fused.C0 + fused.C1) / ((double)fused.stride * fused.stride);
+    const double t_apply = 3.5 + elems * (in_f32 ? 6.0 : 4.0) / 2.8e6;
+    *win = pf->second.us < pu->second.us + t_apply;
+    return SDMI_OK;
+  }
+  int gn_stats(const Act& x, const Act* x1) {
+    GnArgs g;
+    memset(&g, 0, sizeof(g));
+    const bool f32 = x.f != nullptr;
+    g.x0 = f32 ? (const void*)x.f : (const void*)x.h;
+    if (x1) g.x1 = f32 ? (const void*)x1->f : (const void*)x1->h;
+    g.in_f32 = f32; g.C0 = x.C; g.C1 = x1 ? x1->C : 0;
+    g.B = x.B; g.P = x.H * x.W;
+    g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
+    prof_begin(2, 0.0);
+    TRY(sdmi_launch_gn_stats(g, st));
+    prof_end();
+    launches += 1;
+    log_launch("gn_stats C=%d P=%d B=%d", g.C0 + g.C1, g.P, g.B);
+    return SDMI_OK;
+  }
+
   int layernorm(const Act& x, const NormW& w, Act* y) {
     TRY(new_act(x.B, x.H, x.W, x.C, false, y));
     LnArgs l;
@@ -563,6 +645,7 @@ struct Engine {
     TRY(sdmi_launch_layernorm(l, st));
     prof_end();
     launches += 1;
+    log_launch("layernorm M=%d C=%d", l.M, l.C);
     return SDMI_OK;
   }
 
@@ -572,38 +655,69 @@ struct Engine {
     const int cin = x.C + (x1 ? x1->C : 0);
     if (cin != r.cin) { sdmi_set_error("res_block: cin %d vs %d", cin, r.cin); return SDMI_EINVAL; }
     Act t0, h, t1, sk;
-    TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
     TRY(new_act(x.B, x.H, x.W, r.cout, false, &h));
     {
-      GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
-      a.bias = bias1;
-      a.out = h.h; a.ldc = h.C;
+      // GroupNorm -> SiLU -> conv_feature (sd/diffusion.py:173-179): fused (the conv normalises its own A operand from
+      // the raw stream) or the norm writes a normalised tensor the conv re-reads, whichever plan is faster
+      GemmArgs a = base_args(x, x1, r.conv1, x.H, x.W, 1, 0);
+      set_gn(a, r.gn1, 1e-5f, 1);
+      a.bias = bias1; a.out = h.h; a.ldc = h.C;
+      bool fuse = false;
+      if (gn_candidate(a)) {
+        TRY(new_act(x.B, x.H, x.W, cin, false, &t0));
+        GemmArgs u = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
+        u.bias = bias1; u.out = h.h; u.ldc = h.C;
+        TRY(gn_fuse_wins(a, u, x.f != nullptr, &fuse));
+      }
+      if (fuse) {
+        TRY(gn_stats(x, x1));
+      } else {
+        TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
+        a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
+        a.bias = bias1; a.out = h.h; a.ldc = h.C;
+      }
       TRY(gemm(a));
     }
-    TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
     TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
-    GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
-    if (r.has_skip && r.w2s) {
-      // skip 1x1 conv (sd/diffusion.py:143,209) as an extra K-range of conv_merged: one launch, no intermediate
-      a.x0 = x.h; a.X0 = x.C;
-      if (x1) { a.x1 = x1->h; a.X1 = x1->C; }
-      a.K += a.X0 + a.X1;
-      a.w = r.w2s; a.bias = r.bias2s;
-      set_out(a, *y);
-      TRY(gemm(a));
-      return SDMI_OK;
-    }
-    if (r.has_skip) {
+    GemmArgs a = base_args(h, nullptr, r.conv2, x.H, x.W, 1, 0);
+    // finishes conv_merged's arguments (skip segment or residual, outputs) on `g`; the skip GEMM itself is launched by
+    // the caller when the skip conv is not fused
+    auto finish = [&](GemmArgs& g) {
+      if (r.has_skip && r.w2s) {
+        g.x0 = x.h; g.X0 = x.C;
+        if (x1) { g.x1 = x1->h; g.X1 = x1->C; }
+        g.K += g.X0 + g.X1;
+        g.w = r.w2s; g.bias = r.bias2s;
+      } else if (r.has_skip) {
+        set_res(g, sk);
+      } else {
+        set_res(g, x);
+      }
+      set_out(g, *y);
+    };
+    if (r.has_skip && !r.w2s) {
       TRY(new_act(x.B, x.H, x.W, r.cout, true, &sk));
       GemmArgs s = base_args(x, x1, r.skip, x.H, x.W, 1, 0);
       if (sk.f) { s.out = sk.f; s.out_f32 = 1; } else { s.out = sk.h; }
       s.ldc = sk.C;
       TRY(gemm(s));
-      set_res(a, sk);
-    } else {
-      set_res(a, x);
     }
-    set_out(a, *y);
+    set_gn(a, r.gn2, 1e-5f, 1);
+    finish(a);
+    bool fuse2 = false;
+    if (gn_candidate(a)) {
+      TRY(new_act(x.B, x.H, x.W, r.cout, false, &t1));
+      GemmArgs u = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+      finish(u);
+      TRY(gn_fuse_wins(a, u, false, &fuse2));
+    }
+    if (fuse2) {
+      TRY(gn_stats(h, nullptr));
+    } else {
+      TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
+      a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+      finish(a);
+    }
     TRY(gemm(a));
     return SDMI_OK;
   }
@@ -619,6 +733,7 @@ struct Engine {
     TRY(sdmi_launch_attention(t, st));
     prof_end();
     launches += 1;
+    log_launch("attn B=%d H=%d d=%d Sq=%d Skv=%d flops=%.0f", B, kHeads, d, Sq, Skv, 4.0 * B * kHeads * (double)Sq * Skv * d);
     return SDMI_OK;
   }
 

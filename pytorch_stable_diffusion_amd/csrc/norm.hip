@@ -60,7 +60,7 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
   if (tid < 32) {
     const int g = tid;
     const int lo = (g * cpg) / 8, hi = ((g + 1) * cpg - 1) / 8;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;       // fp64 above the per-thread level: the variance is E[x^2] - E[x]^2 (see gn_apply_kernel)
     for (int k = lo; k <= hi; ++k) {
       const int kg0 = (k * 8) / cpg;
       const int sel = (kg0 == g) ? 0 : 2;       // chunk k contributes its first or its second part to g
@@ -71,15 +71,15 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
       }
     }
     float* o = p.partial + (((size_t)n * p.nchunk + chunk) * 32 + g) * 2;
-    o[0] = s;
-    o[1] = q;
+    o[0] = (float)s;
+    o[1] = (float)q;
   }
 }
 
 // grid: (pixel blocks, B); block 256.  Phase 1: all 256 threads reduce the chunk partials (fixed
 // order) to mean/rstd per group; phase 2: normalise (+SiLU) 8-channel chunks.
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_block) {
-  __shared__ float s_red[8][32][2];
+  __shared__ double s_red[8][32][2];
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
   const int n = blockIdx.y;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   }
   {
     const int g = tid & 31, sl = tid >> 5;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
     // nchunk <= 128 -> at most 16 chunks per slice: all loads issued at once (one latency round)
     f32x2 pv[16];
 #pragma unroll
@@ -120,21 +120,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
       pv[k] = ch < p.nchunk ? *(const f32x2*)(p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { s += pv[k][0]; q += pv[k][1]; }
+    for (int k = 0; k < 16; ++k) { s += (double)pv[k][0]; q += (double)pv[k][1]; }
     s_red[sl][g][0] = s;
     s_red[sl][g][1] = q;
   }
   __syncthreads();
   if (tid < 32) {
-    float s = 0.f, q = 0.f;
+    // Variance as E[x^2] - E[x]^2 from fixed-order partial sums.  The cancellation costs eps * (mean/sigma)^2 relative
+    // accuracy, so everything above the per-thread fp32 partials (<= 32 values each) is combined in fp64: measured
+    // (tests/test_gpu_kernels.py::test_groupnorm_large_mean) the output stays within an fp16 ulp up to |mean| = 100 sigma.
+    double s = 0.0, q = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) { s += s_red[sl][tid][0]; q += s_red[sl][tid][1]; }
-    const float cnt = (float)cpg * (float)p.P;
-    const float mean = s / cnt;
-    float var = q / cnt - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    s_mean[tid] = mean;
-    s_rstd[tid] = rsqrtf(var + p.eps);
+    const double cnt = (double)cpg * (double)p.P;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = rsqrtf((float)var + p.eps);
   }
   __syncthreads();
 #pragma unroll
@@ -344,6 +347,22 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   if (ppb < 1) ppb = 1;
   const int nblk = (a.P + ppb - 1) / ppb;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a, ppb);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+// statistics only: partial {sum, sum of squares} per (image, pixel chunk, group) for the fused conv (conv3_gn_kernel)
+int sdmi_launch_gn_stats(const GnArgs& a, hipStream_t st) {
+  const int C = a.C0 + a.C1;
+  SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "gn_stats: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
+  SDMI_REQUIRE(C / 8 <= 320 && C >= 128, "gn_stats: C=%d out of range (128..2560)", C);
+  SDMI_REQUIRE(a.partial && a.x0, "gn_stats: null pointer");
+  SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "gn_stats: nchunk mismatch");
+  const int C8 = C / 8;
+  int PY = 256 / C8;
+  if (PY < 1) PY = 1;
+  const int ppc = (a.P + a.nchunk - 1) / a.nchunk;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(C8 * PY), 0, st, a, PY, ppc);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

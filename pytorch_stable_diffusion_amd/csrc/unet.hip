@@ -150,6 +150,7 @@ int final_layer(sdmi_unet* u, const Act& x, float* eps_out) {
   TRY(u->groupnorm(x, nullptr, u->final_gn, 1e-5f, 1, &t));
   TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, 4, u->st));
   u->launches += 1;
+  u->log_launch("final_conv");
   return SDMI_OK;
 }
 
@@ -288,6 +289,7 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
   TRY(u->enter(stream));
   u->launches = 0;
   u->arena.off = 0;
+  u->launch_log.clear();
   const float* tv;
   if (temb_dev) {
     TRY(u->compute_timevecs(temb_dev, 1, u->timevec_adhoc));
@@ -302,6 +304,7 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
   TRY(sdmi_launch_stem_conv(latents_dev, latent_batch, u->stem_w36, u->stem_bias, x.f ? (void*)x.f : (void*)x.h,
                             x.f != nullptr, x.f ? x.h : nullptr, batch, h, w, u->stem_cout, 4, u->st));
   u->launches += 1;
+  u->log_launch("stem");
   std::vector<Act> skips;
   skips.push_back(x);
   for (size_t i = 1; i < encoders().size(); ++i) {
@@ -319,6 +322,7 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
     x = y;
   }
   TRY(final_layer(u, x, eps_out_dev));
+  u->write_launch_log();
   return SDMI_OK;
 }
 
@@ -435,6 +439,8 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt; a.tperm = d->out_t_perm;
   a.x0 = (const f16*)d->x0; a.x1 = (const f16*)d->x1; a.X0 = d->cx0; a.X1 = d->cx1;
   a.rowstat = d->rowstat; a.ln_stat = d->ln_stat; a.ln_ntn = d->ln_ntn; a.ln_g = d->ln_g; a.ln_C = d->ln_c; a.ln_eps = d->ln_eps;
+  a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta;
+  a.gn_eps = d->gn_eps; a.gn_silu = d->gn_silu;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
@@ -493,6 +499,15 @@ int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1
   g.x0 = x0; g.x1 = x1; g.in_f32 = in_f32; g.C0 = c0; g.C1 = c1; g.B = B; g.P = P; g.gamma = gamma; g.beta = beta;
   g.eps = eps; g.silu = silu; g.y = (f16*)y_f16; g.partial = partial; g.nchunk = sdmi_gn_nchunk(P);
   return sdmi_launch_groupnorm(g, (hipStream_t)stream);
+}
+
+int sdmi_gn_num_chunks(int P) { return sdmi_gn_nchunk(P); }
+int sdmi_op_gn_stats(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, float* partial_out, void* stream) {
+  GnArgs g;
+  memset(&g, 0, sizeof(g));
+  g.x0 = x0; g.x1 = x1; g.in_f32 = in_f32; g.C0 = c0; g.C1 = c1; g.B = B; g.P = P;
+  g.partial = partial_out; g.nchunk = sdmi_gn_nchunk(P);
+  return sdmi_launch_gn_stats(g, (hipStream_t)stream);
 }
 
 int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Join rocprofv3 output with the engine's launch log (SDMI_LAUNCH_LOG): which SHAPE each kernel of a denoising step ran.
+
+  kernel trace  : join_trace.py time <kernel_trace.csv> <launch_log.txt> [step]
+                  -> per shape: launches, us, TF/s, weight GB/s
+  PMC passes    : join_trace.py pmc <fetch counter_collection.csv> <write counter_collection.csv> <launch_log.txt> <out.json>
+                  -> per shape: FETCH (x2, gfx950 correction, MI355X_MICROARCH.md) + WRITE bytes per step vs the
+                     algorithmic bytes (weights once + activations in/out once)
+  MFMA busy     : join_trace.py mfma <counter_collection.csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> <launch_log.txt> <out.json>
+
+A step = the kernels from stem_conv to cfg_ddpm; log line i is matched to the i-th kernel of the step whose name fits the
+line's kind (fill kernels of hipMemsetAsync and anything else unknown are skipped)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+KIND_PAT = {"igemm": "igemm_kernel", "halo": "conv3_halo_kernel", "finalize": "splitk_finalize", "attn": "attn_kernel",
+            "gn_fused": "gn_fused_kernel", "gn_stats": "gn_stats_kernel", "gn_apply": "gn_apply_kernel",
+            "layernorm": "layernorm_kernel", "stem": "stem_conv", "final_conv": "final_conv", "xattn": "xattn"}
+
+
+def read_rows(path):
+    """kernel rows of a rocprofv3 run: a kernel_trace CSV, or the rocpd sqlite database newer rocprofv3 writes by default"""
+    if path.endswith(".db"):
+        import sqlite3
+        con = sqlite3.connect(path)
+        cur = con.execute("select name, start, end, grid_x, workgroup_x from kernels")
+        return [{"Kernel_Name": n, "Start_Timestamp": str(s), "End_Timestamp": str(e), "Grid_Size_X": g, "Workgroup_Size_X": w}
+                for n, s, e, g, w in cur]
+    return list(csv.DictReader(open(path)))
+
+
+def read_log(path):
+    out = []
+    for ln in open(path):
+        ln = ln.strip()
+        if not ln:
+            continue
+        kind = ln.split()[0]
+        kv = dict(re.findall(r"(\w+)=(\S+)", ln))
+        out.append((kind, kv, ln))
+    return out
+
+
+def steps_of(rows):
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "stem_conv" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "cfg_ddpm" in r["Kernel_Name"]]
+    out = []
+    for s in starts:
+        e = next((x for x in ends if x > s), None)
+        if e is not None:
+            out.append(rows[s:e + 1])
+    return out
+
+
+def align(step_rows, log):
+    """-> list of (log entry, row) ; raises if a log entry finds no kernel"""
+    j, out = 0, []
+    for kind, kv, text in log:
+        pat = KIND_PAT.get(kind, kind)
+        while j < len(step_rows) and pat not in step_rows[j]["Kernel_Name"]:
+            j += 1
+        if j >= len(step_rows):
+            raise SystemExit(f"launch log entry '{text}' has no kernel left in the step ({len(step_rows)} kernels)")
+        out.append(((kind, kv, text), step_rows[j]))
+        j += 1
+    return out
+
+
+def shape_key(kind, kv):
+    if kind in ("igemm", "halo", "finalize"):
+        return f"{kind:8s} M={kv['M']:>5s} N={kv['N']:>5s} K={kv['K']:>5s}" + (f" ks={kv['ks']} s={kv['s']} up={kv['up']} {kv['cfg']} split {kv['split']}" if kind != "finalize" else f" split {kv['split']}")
+    if kind == "attn":
+        return f"attn     d={kv['d']} Sq={kv['Sq']} Skv={kv['Skv']}"
+    if kind.startswith("gn") or kind == "layernorm":
+        return f"{kind:8s} " + " ".join(f"{k}={v}" for k, v in kv.items())
+    return kind
+
+
+def cmd_time(trace, logp, which=None):
+    rows = read_rows(trace)
+    steps = steps_of(rows)
+    log = read_log(logp)
+    step = steps[int(which) if which is not None else min(15, len(steps) - 1)]
+    agg = collections.OrderedDict()
+    for (kind, kv, _), r in align(step, log):
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg.setdefault(shape_key(kind, kv), [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += us
+        a[2] += float(kv.get("flops", 0))
+        a[3] += float(kv.get("wbytes", 0))
+    tot = sum(a[1] for a in agg.values())
+    print(f"{len(step)} kernels in the step, {sum(a[0] for a in agg.values())} matched, {tot:.1f} us")
+    for k, (n, us, fl, wb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        extra = f"  {fl / us * 1e-6:7.1f} TF/s  {wb / us * 1e-3:7.1f} GB/s weights" if fl else ""
+        print(f"  {k:78s} x{n:3d} {us:8.1f} us  avg {us / n:7.2f}{extra}")
+
+
+def pmc_rows(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    return steps_of(rows)
+
+
+def cmd_pmc(fetch_csv, write_csv, logp, outp):
+    log = read_log(logp)
+    res = collections.OrderedDict()
+    nsteps = {}
+    for counter, path, scale in (("FETCH_SIZE", fetch_csv, 2 * 1024.0), ("WRITE_SIZE", write_csv, 1024.0)):
+        steps = pmc_rows(path, counter)[-8:]
+        nsteps[counter] = len(steps)
+        for step in steps:
+            for (kind, kv, _), r in align(step, log):
+                e = res.setdefault(shape_key(kind, kv), {"launches_per_step": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "algorithmic": 0.0, "kind": kind})
+                e[counter] += float(r["Counter_Value"]) * scale / len(steps)
+                if counter == "FETCH_SIZE":
+                    e["launches_per_step"] += 1.0 / len(steps)
+                    if kind in ("igemm", "halo"):
+                        M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
+                        ks = int(kv["ks"])
+                        a_in = M * (K // (ks * ks)) * 2 * (int(kv["s"]) ** 2) / (4 if kv["up"] == "1" else 1)
+                        out_b = M * N * (6 if kv.get("out32") == "1" else 2) + (M * N * 4 if kv.get("res") == "1" else 0)
+                        e["algorithmic"] += (N * K * 2 + a_in + out_b) / len(steps)
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
+    for k, e in res.items():
+        f = "igemm" if e["kind"] in ("igemm", "halo", "finalize") else ("attn" if e["kind"] in ("attn", "xattn") else ("norm" if e["kind"].startswith(("gn", "layer")) else "other"))
+        fam[f][0] += e["FETCH_SIZE"]; fam[f][1] += e["WRITE_SIZE"]; fam[f][2] += e["launches_per_step"]
+        e["hbm_bytes"] = e["FETCH_SIZE"] + e["WRITE_SIZE"]
+        e["launches_per_step"] = round(e["launches_per_step"], 2)
+    out = {"note": "per denoising step, mean of the last 8 steps of each pass; FETCH_SIZE x2 (gfx950 reports half of wide reads, "
+                   "MI355X_MICROARCH.md); separate rocprofv3 --pmc passes; joined with the engine's launch log by tools/join_trace.py. "
+                   "'algorithmic' = weights once + input activations once + outputs (and residual) once, per GEMM shape.",
+           "steps_averaged": nsteps, "launch_log_entries": len(log),
+           "families": {f: {"fetch_bytes": v[0], "write_bytes": v[1], "hbm_bytes": v[0] + v[1], "launches": round(v[2])} for f, v in fam.items()},
+           "by_shape": collections.OrderedDict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes"]))}
+    json.dump(out, open(outp, "w"), indent=1)
+    print(json.dumps(out["families"], indent=1))
+    for k, e in list(out["by_shape"].items())[:25]:
+        print(f"  {k:78s} x{e['launches_per_step']:5.1f} fetch {e['FETCH_SIZE']/1e6:8.1f} MB write {e['WRITE_SIZE']/1e6:7.1f} MB  algorithmic {e['algorithmic']/1e6:7.1f} MB")
+
+
+def cmd_mfma(csv_path, logp, outp):
+    log = read_log(logp)
+    allrows = list(csv.DictReader(open(csv_path)))
+    by_counter = collections.defaultdict(list)
+    for r in allrows:
+        by_counter[r["Counter_Name"]].append(r)
+    per = collections.OrderedDict()
+    for counter, rows in by_counter.items():
+        steps = steps_of(rows)[-8:]
+        for step in steps:
+            for (kind, kv, _), r in align(step, log):
+                fam = "igemm" if kind in ("igemm", "halo") else kind
+                e = per.setdefault(fam, collections.defaultdict(float))
+                e[counter] += float(r["Counter_Value"]) / len(steps)
+                if counter == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    e["launches"] += 1.0 / len(steps)
+    out = {"note": "per denoising step; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES summed over the launches of each family "
+                   "(rocprofv3 --pmc, one pass; both counters are summed over all SEs/XCDs by rocprofv3). "
+                   "mfma_busy_frac = MFMA-busy cycles / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs) when GRBM_GUI_ACTIVE is present, "
+                   "else / SQ_BUSY_CYCLES-normalised as stated per entry.", "families": {}}
+    for fam, e in per.items():
+        d = dict(e)
+        if d.get("SQ_BUSY_CYCLES"):
+            d["mfma_busy_over_sq_busy"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / d["SQ_BUSY_CYCLES"]
+        if d.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_frac_of_chip"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        out["families"][fam] = d
+    json.dump(out, open(outp, "w"), indent=1)
+    print(json.dumps(out["families"], indent=1))
+
+
+if __name__ == "__main__":
+    c = sys.argv[1]
+    if c == "time":
+        cmd_time(*sys.argv[2:5])
+    elif c == "pmc":
+        cmd_pmc(*sys.argv[2:6])
+    elif c == "mfma":
+        cmd_mfma(*sys.argv[2:5])
+    else:
+        raise SystemExit(__doc__)
