@@ -179,19 +179,39 @@ def main():
         ig = pr["igemm"]
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         scale = (hw / 64.0) ** 2
-        # HBM/fabric bytes per step of the same kernel family, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # passes around this command (FETCH_SIZE x2: gfx950 correction), committed under profiles/
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01z_hbm_traffic.json")
+        # HBM/fabric bytes per step of the same kernel family and its MFMA-busy fraction come from separate rocprofv3 --pmc
+        # passes around THIS command (tools/profile_r02.sh; FETCH_SIZE x2: gfx950 correction), committed under profiles/.
+        # They are only quoted when that profile saw the launch structure this run has (same launches per step): a
+        # profile of other kernels is refused rather than reported stale.
+        launches_now = h.last_launch_count + 1
+        traffic, traffic_src, mfma_busy, mfma_src = None, None, None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_by_shape.json")
         if hw == 64 and os.path.exists(tpath):
             with open(tpath) as tf:
-                traffic = round(json.load(tf)["per_step"]["igemm"]["hbm_bytes"] / 1e9, 3)
-            traffic_src = "profiles/r01z_hbm_traffic.json (GB per step, PMC passes of an earlier run of this command)"
+                tj = json.load(tf)
+            if tj.get("bench_launches_per_step") == launches_now:
+                traffic = round(tj["families"]["igemm"]["hbm_bytes"] / 1e9, 3)
+                traffic_src = "profiles/r02_hbm_traffic_by_shape.json (GB per step over the family's launches)"
+            else:
+                traffic_src = (f"refused: profiles/r02_hbm_traffic_by_shape.json was taken at {tj.get('bench_launches_per_step')} "
+                               f"launches/step, this run has {launches_now}")
+        mpath = os.path.join(ROOT, "profiles", "r02_mfma_busy.json")
+        if hw == 64 and os.path.exists(mpath):
+            with open(mpath) as mf:
+                mj = json.load(mf)
+            if mj.get("bench_launches_per_step") == launches_now:
+                mfma_busy = round(mj["families"]["igemm"]["mfma_busy_frac_of_chip"], 4)
+                mfma_src = "profiles/r02_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family's launches"
+            else:
+                mfma_src = f"refused: profile taken at {mj.get('bench_launches_per_step')} launches/step, this run has {launches_now}"
         roof = {
             "bound": "mfma", "kernel": "igemm_kernel + conv3_halo_kernel (all conv3x3/conv1x1/linear launches of a step)",
             "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "GB/step",
-            "traffic_source": traffic_src, "algorithmic_bytes_per_step_GB": 1.62 + 2.6,
+            "frac": round(achieved / PEAK_TFLOPS_F16, 4), "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src,
+            "traffic": traffic, "traffic_unit": "GB/step", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_step_GB": 1.62,
+            "algorithmic_bytes_note": "SURVEY 8d floor: the live fp16 weights once per step; activations (2.6 GB/step if every "
+                                      "GEMM input/output round-tripped HBM once) are not part of the floor",
             "launches_per_step": ig["launches"] // nprof,
             "gflop_per_step": round(ig["flops"] / nprof / 1e9, 2),
             "ms_per_step": round(ig["ms"] / nprof, 3),
@@ -252,6 +272,26 @@ def main():
                "kind": "port",
                "sample": f"{args.cpu_steps} CFG denoising steps (batch-2 UNet + CFG + DDPM), {hw}x{hw} latents, fp32, "
                          f"oracle on torch-CPU, {dt:.1f} s"}
+        if args.cpu_config1:
+            # BASELINE configs[0] end to end on the host: CLIP x2 + 20 CFG steps + VAE decode, all through the oracle
+            from oracle import aux_ref
+            from pytorch_stable_diffusion_amd import model_loader
+            from tests.stub_tokenizer import StubTokenizer
+            aux = model_loader.synthetic_state_dicts(("clip", "decoder"))
+            tok = StubTokenizer()
+            t1 = time.perf_counter()
+            ids = lambda t: torch.tensor(tok.batch_encode_plus([t], padding="max_length", max_length=77).input_ids)
+            ctx_c = torch.cat([aux_ref.clip_forward(aux["clip"], ids("a dog")), aux_ref.clip_forward(aux["clip"], ids(""))])
+            sched1 = ddpm_ref.RefSchedule()
+            sched1.set_inference_timesteps(20)
+            g3 = torch.Generator().manual_seed(42)
+            lat1 = torch.randn((1, 4, hw, hw), generator=g3)
+            lat1 = ddpm_ref.denoise_loop(lambda x, c, t: unet_ref.diffusion_forward(sd_cpu, x, c, t), lat1, ctx_c, sched1, g3)
+            img = aux_ref.vae_decode(aux["decoder"], lat1)
+            dt1 = time.perf_counter() - t1
+            cpu["config1_end_to_end_s"] = round(dt1, 1)
+            cpu["config1_note"] = ("BASELINE configs[0]: txt2img 512x512, 20 DDPM steps, CFG 7.5, CPU fp32 (oracle CLIP x2 + 20 "
+                                   f"steps + VAE decoder), image {tuple(img.shape)}; the reference itself: 155.95 s on 8 threads (SURVEY 6)")
 
     if rank == 0:
         total_steps = args.steps * world

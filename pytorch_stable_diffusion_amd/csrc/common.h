@@ -80,6 +80,7 @@ struct GemmArgs {
   float* slab;
   int ksplit;
   int ksteps_per;
+  int n_major;         // tile order inside a K-slice, set by the launcher (gemm.hip): 1 = consecutive tiles walk m first
   int act;             // epilogue activation after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170)
   // LayerNorm folded around the GEMM (sd/diffusion.py:317,334,351 feeding 321/339/356):
   //  producer side: rowstat != null -> the epilogue also writes per-row {sum, sum of squares} of the fp16 output

@@ -757,8 +757,14 @@ struct Engine {
     const int B = x.B, S = x.H * x.W, C = w.C;
     const int Spad = ((S + 63) / 64) * 64;
     Act t0, s0, u, qk, ao, s1, q2, s2, g;
+    // The block's INNER stream (s0 -> s1 -> s2: three additions, sd/diffusion.py:321-363) can be kept in fp16 only
+    // (SDMI_ATTN_INNER_F16=1): each of these tensors is a 10.5 MB fp32 write + a 10.5 MB fp32 read per GEMM at 64x64, half
+    // the traffic of the four K = C GEMMs that are bound by it.  Measured on one MI355X (same box, same plans): 205.6 vs
+    // 202.3 steps/s, attention blocks rel-L2 1.9e-4 vs 1.6e-4, 50-step txt2img pixel MAE 6.97e-4 vs 6.30e-4.  The default
+    // keeps the fp32 copies: 1.6 % of speed is not worth 10 % of the parity budget.
+    static const bool inner_f32 = getenv("SDMI_ATTN_INNER_F16") == nullptr;
     TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
-    TRY(new_act(B, x.H, x.W, C, true, &s0));
+    TRY(new_act(B, x.H, x.W, C, inner_f32, &s0));
     RowStat rs;
     { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
     // self-attention
@@ -777,7 +783,7 @@ struct Engine {
     }
     TRY(new_act(B, x.H, x.W, C, false, &ao));
     TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
-    TRY(new_act(B, x.H, x.W, C, true, &s1));
+    TRY(new_act(B, x.H, x.W, C, inner_f32, &s1));
     { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a, &rs)); }
     // cross-attention (K/V hoisted in set_context)
     if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
@@ -790,7 +796,7 @@ struct Engine {
       TRY(gemm(a));
     }
     TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
-    TRY(new_act(B, x.H, x.W, C, true, &s2));
+    TRY(new_act(B, x.H, x.W, C, inner_f32, &s2));
     { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
     // feed-forward: first half of linear_geglu_1 only (reference discards the gate)
     if (!rs.ptr) TRY(layernorm(s2, w.ln3, &u));

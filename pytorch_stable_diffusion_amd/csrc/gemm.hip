@@ -257,7 +257,12 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     kz = L / tiles;
     tile = L - kz * tiles;
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
+  // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
+  // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
+  const int tiles_m = tiles / tiles_n;
+  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
+  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = p.K >> 6;
   const int kt0 = kz * p.ksteps_per;
@@ -622,7 +627,12 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
     kz = L / tiles;
     tile = L - kz * tiles;
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
+  // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
+  // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
+  const int tiles_m = tiles / tiles_n;
+  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
+  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int Cin = p.C0 + p.C1, nchunk = Cin >> 6;
   const int nkt = 9 * nchunk;
@@ -930,7 +940,12 @@ __global__ __launch_bounds__(C::NT) void conv3_gn_kernel(GemmArgs p, int halo_by
     kz = L / tiles;
     tile = L - kz * tiles;
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
+  // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
+  // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
+  const int tiles_m = tiles / tiles_n;
+  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
+  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   int Cin = p.C0 + p.C1;
   int NCm = Cin >> 6;
@@ -1567,6 +1582,12 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(p.lda0 % 8 == 0 && p.lda1 % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
   if (p.ksplit < 1) p.ksplit = 1;
   if (p.ksplit > nkt) p.ksplit = nkt;
+  {
+    static const int force = getenv("SDMI_TILE_ORDER") ? atoi(getenv("SDMI_TILE_ORDER")) : -1;   // A/B knob: 0 m-major, 1 n-major
+    const double w_bytes = 2.0 * a.N * a.K;
+    const double a_bytes = 2.0 * ((double)a.M * a.stride * a.stride / (a.ups ? 4 : 1)) * (a.C0 + a.C1) + 2.0 * a.M * (a.X0 + a.X1);
+    p.n_major = force >= 0 ? force : (w_bytes > a_bytes);
+  }
   p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
   if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
   p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits

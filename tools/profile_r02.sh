@@ -1,0 +1,37 @@
+#!/bin/bash
+# One-call profiling recipe on the GPU box (run through gpurun from the repo root):
+#   kernel trace + launch log -> per-shape times; separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy | MFMA ops)
+# Counter passes carry only --kernel-trace besides --pmc (gpurun refuses other trace domains with counters).
+set -e
+tag=${1:-r02}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+export SDMI_LAUNCH_LOG=$PWD/$out/launch_log.txt
+B="python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/bench_trace.json 2> $out/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B > /dev/null 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B > /dev/null 2> $out/write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/mfma -o m -- $B > /dev/null 2> $out/mfma.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/mops -o o -- $B > /dev/null 2> $out/mops.err
+find $out -name "*.csv" | head -20
+python3 tools/join_trace.py time $(find $out/trace -name "*kernel_trace.csv") $out/launch_log.txt > $out/step_by_shape.txt
+python3 tools/join_trace.py pmc $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/launch_log.txt $out/hbm_traffic_by_shape.json > $out/pmc_summary.txt
+python3 tools/join_trace.py mfma $(find $out/mfma -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_busy.json > $out/mfma_summary.txt
+python3 tools/join_trace.py mfma $(find $out/mops -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_ops.json > $out/mops_summary.txt
+cp $(find $out/trace -name "*kernel_stats.csv") $out/kernel_stats.csv
+python3 - "$out" <<'PY'
+import json, sys
+out = sys.argv[1]
+b = json.loads(open(f"{out}/bench_trace.json").read().strip().splitlines()[-1])
+n = b["config"]["launches_per_step"]
+for f in ("hbm_traffic_by_shape.json", "mfma_busy.json", "mfma_ops.json"):
+    j = json.load(open(f"{out}/{f}"))
+    j["bench_launches_per_step"] = n
+    j["bench_command"] = "python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency (under rocprofv3 --pmc ...)"
+    json.dump(j, open(f"{out}/{f}", "w"), indent=1)
+print("launches/step", n)
+PY
+# the raw CSVs are large: keep only the summaries (the merge back is capped at 64 MiB)
+rm -rf $out/trace $out/fetch $out/write $out/mfma $out/mops
+ls -la $out
