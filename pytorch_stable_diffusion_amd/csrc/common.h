@@ -92,6 +92,11 @@ struct GemmArgs {
   float cscale; int cs_hi;
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_C; float ln_eps;
+  //  ln_ksteps > 0: only the FIRST ln_ksteps K-steps (of 64) are the LayerNorm-folded segment; after them the accumulator is
+  //    rescaled in registers, acc = rstd[m]*(acc - mean[m]*ln_g[n]), and the remaining K-steps accumulate a plain product
+  //    on top (the composed feed-forward of the attention block: y = LN(s) Wf^T + s Wo^T + b + x in one GEMM); the
+  //    epilogue is then the plain bias (+ residual) one.  0: the whole K range is folded (epilogue form above).
+  int ln_ksteps;
   // GroupNorm(32) (+SiLU) of the A operand fused into the 3x3 conv (conv3_gn_kernel; sd/diffusion.py:173-179,199-205):
   // a0 | a1 are the RAW activations; gn_partial = gn_stats_kernel's per-chunk {sum, sum of squares} per group
   // ([B][gn_nchunk][32][2]), reduced in the conv's prologue; y = silu(x * (rstd gamma) + (beta - mean rstd gamma)) is
@@ -180,8 +185,8 @@ int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* l
 int sdmi_launch_add_vec(const float* a, const float* b, float* y, size_t n, hipStream_t st);
 int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, const float* beta, const float* bias,
                             f16* w_out, float* g_out, float* h_out, int N, int C, hipStream_t st);
-int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, f16* out, int N, int K, int J, int ldo,
-                               hipStream_t st);
+int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, void* out, int out_f32, int N, int K, int J,
+                               int ldo, hipStream_t st);
 int sdmi_launch_compose_bias(const void* A, int a_f32, const float* b_in, const float* b_out, float* out, int N, int K,
                              hipStream_t st);
 int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int cols, int ld, hipStream_t st);

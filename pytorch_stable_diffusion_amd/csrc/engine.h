@@ -48,9 +48,15 @@ struct RowStat { const float* ptr = nullptr; int ntn = 0; };
 
 struct AttnW {
   NormW gn, ln1, ln2, ln3;
-  ConvW conv_in, in_proj, out1, q, k, v, out2, g1;
-  FoldW in_proj_f, q_f, g1_f;      // layernorm_1/2/3 folded into in_proj / q_proj / linear_geglu_1
-  ConvW tail;                      // conv_output o linear_geglu_2 composed: [C][4C | C] over the inputs (geglu | s2)
+  ConvW conv_in, in_proj, out1, q, k, v, out2;
+  FoldW in_proj_f, q_f;            // layernorm_1/2 folded into in_proj / q_proj
+  // The block's feed-forward and output conv are ONE linear map of (LN3(s2), s2): the reference discards the GeGLU gate
+  // (quirk Q2, sd/diffusion.py:359), so nothing non-linear sits between linear_geglu_1, linear_geglu_2 and conv_output:
+  //   y = Wo (W2 (W1a LN3(s2) + b1a) + b2 + s2) + bo + x = Wf LN3(s2) + Wo s2 + bf + x,  Wf = Wo W2 W1a (C x C).
+  // ffn: [C][2C] fp16 = [Wf | Wo] over the virtual concat [LN3(s2) | s2], bias bf;  ffn_f: the same with layernorm_3
+  // folded into the first C columns ([gamma (.) Wf | Wo], g, h) for the partial LayerNorm fold (GemmArgs::ln_ksteps).
+  ConvW ffn;
+  FoldW ffn_f;
   int C = 0, dh = 0, ctx_idx = 0;
 };
 struct Act {
@@ -343,30 +349,54 @@ struct Engine {
     res_order.push_back(p);
     return SDMI_OK;
   }
-  // y = conv_output(linear_geglu_2(g) + s2) + x  (sd/diffusion.py:363-381) is linear in (g, s2): composed at load into
-  // ONE GEMM over the virtual concat [g | s2]:  W = [Wo W2 | Wo] (fp32 product, rounded once), b = Wo b2 + bo.
-  // Same FLOPs as the two GEMMs, one launch and one (M, C) fp32 round trip fewer per attention block.
-  int load_tail(const std::string& p, int C, AttnW* a) {
-    const sdmi_tensor_desc *w2, *wo, *b2, *bo;
+  // Composes the attention block's feed-forward + conv_output (sd/diffusion.py:351-381) into one [C][2C] GEMM at load
+  // (AttnW::ffn / ffn_f).  All products in fp32 on the device, rounded to fp16 once; temporaries are freed again.
+  int load_ffn(const std::string& p, int C, AttnW* a) {
+    const sdmi_tensor_desc *w1, *b1, *w2, *b2, *wo, *bo;
+    TRY(need(p + ".linear_geglu_1.weight", &w1, 2, {8 * C, C}));
+    TRY(need(p + ".linear_geglu_1.bias", &b1, 1, {8 * C}));
     TRY(need(p + ".linear_geglu_2.weight", &w2, 2, {C, 4 * C}));
     TRY(need(p + ".linear_geglu_2.bias", &b2, 1, {C}));
     if (find(p + ".conv_output.weight") && find(p + ".conv_output.weight")->ndim == 2) TRY(need(p + ".conv_output.weight", &wo, 2, {C, C}));
     else TRY(need(p + ".conv_output.weight", &wo, 4, {C, C, 1, 1}));
     TRY(need(p + ".conv_output.bias", &bo, 1, {C}));
-    ConvW& t = a->tail;
-    t.O = C; t.I = 5 * C; t.ks = 1;
-    TRY(dmalloc(&t.w, (size_t)C * 5 * C * 2));
-    TRY(dmalloc(&t.bias, (size_t)C * 4));
-    float *b2f, *bof;
-    TRY(dmalloc(&b2f, (size_t)C * 4));
-    TRY(dmalloc(&bof, (size_t)C * 4));
-    TRY(sdmi_launch_cast_any_f32(b2->data_dev, b2->dtype == SDMI_F32, b2f, C, st));
-    TRY(sdmi_launch_cast_any_f32(bo->data_dev, bo->dtype == SDMI_F32, bof, C, st));
-    TRY(sdmi_launch_compose_linear(wo->data_dev, wo->dtype == SDMI_F32, w2->data_dev, w2->dtype == SDMI_F32, t.w, C, C, 4 * C, 5 * C, st));
-    TRY(sdmi_launch_cast_rows(wo->data_dev, wo->dtype == SDMI_F32, t.w + 4 * C, C, C, 5 * C, st));
-    TRY(sdmi_launch_compose_bias(wo->data_dev, wo->dtype == SDMI_F32, b2f, bof, t.bias, C, C, st));
-    weight_bytes += (int64_t)C * 5 * C * 2 + (int64_t)C * 4;
-    return SDMI_OK;
+    const bool w1f = w1->dtype == SDMI_F32, w2f = w2->dtype == SDMI_F32, wof = wo->dtype == SDMI_F32;
+    float *t1 = nullptr, *wf = nullptr, *vec = nullptr;     // T1 = Wo W2 [C][4C], Wf = T1 W1a [C][C], 4 vectors
+    SDMI_CHECK_HIP(hipMalloc((void**)&t1, (size_t)C * 4 * C * 4));
+    SDMI_CHECK_HIP(hipMalloc((void**)&wf, (size_t)C * C * 4));
+    SDMI_CHECK_HIP(hipMalloc((void**)&vec, (size_t)(4 * C + 3 * C) * 4));
+    float *b1a = vec, *b2f = vec + 4 * C, *bof = b2f + C, *bt = bof + C;
+    auto done = [&](int rc) { (void)hipStreamSynchronize(st); (void)hipFree(t1); (void)hipFree(wf); (void)hipFree(vec); return rc; };
+    int rc;
+    // quirk Q2: only rows [0, 4C) of linear_geglu_1 (the un-gated half) reach the output
+    if ((rc = sdmi_launch_cast_any_f32(b1->data_dev, b1->dtype == SDMI_F32, b1a, 4 * C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_cast_any_f32(b2->data_dev, b2->dtype == SDMI_F32, b2f, C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_cast_any_f32(bo->data_dev, bo->dtype == SDMI_F32, bof, C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_compose_linear(wo->data_dev, wof, w2->data_dev, w2f, t1, 1, C, C, 4 * C, 4 * C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_compose_linear(t1, 1, w1->data_dev, w1f, wf, 1, C, 4 * C, C, C, st)) != SDMI_OK) return done(rc);
+    ConvW& f = a->ffn;
+    f.O = C; f.I = 2 * C; f.ks = 1;
+    if ((rc = dmalloc(&f.w, (size_t)C * 2 * C * 2)) != SDMI_OK) return done(rc);
+    if ((rc = dmalloc(&f.bias, (size_t)C * 4)) != SDMI_OK) return done(rc);
+    // bf = T1 b1a + (Wo b2 + bo)
+    if ((rc = sdmi_launch_compose_bias(wo->data_dev, wof, b2f, bof, bt, C, C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_compose_bias(t1, 1, b1a, bt, f.bias, C, 4 * C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_cast_rows(wf, 1, f.w, C, C, 2 * C, st)) != SDMI_OK) return done(rc);
+    if ((rc = sdmi_launch_cast_rows(wo->data_dev, wof, f.w + C, C, C, 2 * C, st)) != SDMI_OK) return done(rc);
+    // layernorm_3 folded into the Wf half
+    FoldW& ff = a->ffn_f;
+    f16* wfold = nullptr;
+    if ((rc = dmalloc(&ff.w, (size_t)C * 2 * C * 2)) != SDMI_OK) return done(rc);
+    if ((rc = dmalloc(&ff.g, (size_t)C * 4)) != SDMI_OK) return done(rc);
+    if ((rc = dmalloc(&ff.h, (size_t)C * 4)) != SDMI_OK) return done(rc);
+    if (hipMalloc((void**)&wfold, (size_t)C * C * 2) != hipSuccess) { sdmi_set_error("hipMalloc failed"); return done(SDMI_ENOMEM); }
+    rc = sdmi_launch_ln_fold_prep(wf, 1, a->ln3.gamma, a->ln3.beta, f.bias, wfold, ff.g, ff.h, C, C, st);
+    if (rc == SDMI_OK && hipMemcpy2DAsync(ff.w, (size_t)2 * C * 2, wfold, (size_t)C * 2, (size_t)C * 2, C, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SDMI_EHIP;
+    if (rc == SDMI_OK) rc = sdmi_launch_cast_rows(wo->data_dev, wof, ff.w + C, C, C, 2 * C, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(wfold);
+    weight_bytes += (int64_t)2 * C * 2 * C * 2 + (int64_t)3 * C * 4;
+    return done(rc);
   }
   // first N rows of Linear `p` ([O][C], O >= N) with LayerNorm `ln` folded in
   int load_fold(const std::string& p, int N, int C, const NormW& ln, const float* bias, FoldW* f) {
@@ -395,12 +425,9 @@ struct Engine {
     TRY(load_conv(p + ".attention_2.v_proj", C, kCtx, 1, false, &a.v));
     TRY(load_conv(p + ".attention_2.out_proj", C, C, 1, true, &a.out2));
     TRY(load_norm(p + ".layernorm_3", C, &a.ln3));
-    // quirk Q2 (sd/diffusion.py:359-363): only the first 4C output rows of linear_geglu_1 are live
-    TRY(load_conv(p + ".linear_geglu_1", 8 * C, C, 1, true, &a.g1, 4 * C));
-    TRY(load_tail(p, C, &a));
+    TRY(load_ffn(p, C, &a));
     TRY(load_fold(p + ".attention_1.in_proj", 3 * C, C, a.ln1, nullptr, &a.in_proj_f));
     TRY(load_fold(p + ".attention_2.q_proj", C, C, a.ln2, nullptr, &a.q_f));
-    TRY(load_fold(p + ".linear_geglu_1", 4 * C, C, a.ln3, a.g1.bias, &a.g1_f));
     a.ctx_idx = (int)attn_order.size();
     attn[p] = a;
     attn_order.push_back(p);
@@ -756,7 +783,7 @@ struct Engine {
     }
     const int B = x.B, S = x.H * x.W, C = w.C;
     const int Spad = ((S + 63) / 64) * 64;
-    Act t0, s0, u, qk, ao, s1, q2, s2, g;
+    Act t0, s0, u, qk, ao, s1, q2, s2;
     // The block's INNER stream (s0 -> s1 -> s2: three additions, sd/diffusion.py:321-363) can be kept in fp16 only
     // (SDMI_ATTN_INNER_F16=1): each of these tensors is a 10.5 MB fp32 write + a 10.5 MB fp32 read per GEMM at 64x64, half
     // the traffic of the four K = C GEMMs that are bound by it.  Measured on one MI355X (same box, same plans): 205.6 vs
@@ -798,17 +825,16 @@ struct Engine {
     TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s2));
     { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
-    // feed-forward: first half of linear_geglu_1 only (reference discards the gate)
+    // feed-forward + conv_output + the block's long residual: ONE GEMM over [LN3(s2) | s2] (AttnW::ffn)
     if (!rs.ptr) TRY(layernorm(s2, w.ln3, &u));
-    TRY(new_act(B, x.H, x.W, 4 * C, false, &g));
+    TRY(new_act(B, x.H, x.W, C, true, y));
     {
-      GemmArgs a = base_args(rs.ptr ? s2 : u, nullptr, w.g1, x.H, x.W, 1, 0);
-      if (rs.ptr) fold_ln(a, w.g1_f, rs, C);
-      a.out = g.h; a.ldc = 4 * C;
+      GemmArgs a = base_args(rs.ptr ? s2 : u, &s2, w.ffn, x.H, x.W, 1, 0);
+      if (rs.ptr) { fold_ln(a, w.ffn_f, rs, C); a.ln_ksteps = C / 64; }
+      set_res(a, x);
+      set_out(a, *y);
       TRY(gemm(a));
     }
-    TRY(new_act(B, x.H, x.W, C, true, y));
-    { GemmArgs a = base_args(g, &s2, w.tail, x.H, x.W, 1, 0); set_res(a, x); set_out(a, *y); TRY(gemm(a)); }
     return SDMI_OK;
   }
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     constexpr int ITEMS = (BM * (BN / 8) + NT - 1) / NT;
     constexpr int CH = ITEMS < 4 ? ITEMS : (NT >= 1024 ? 2 : 4);    // 1024-thread workgroups: 128 VGPRs per lane
     static_assert(ITEMS % CH == 0, "epilogue chunking");
-    const bool fold = p.ln_stat != nullptr;
+    const bool fold = p.ln_stat != nullptr && p.ln_ksteps == 0;
 #pragma unroll
     for (int ch = 0; ch < ITEMS; ch += CH) {
     f32x4 r0[CH], r1[CH], b0[CH], b1[CH];
@@ -200,7 +200,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = Cs[(r8 * 8 + e) * BN + col];
-        if (p.ln_stat) v = s_ln[2 * (r8 * 8 + e) + 1] * (v - s_ln[2 * (r8 * 8 + e)] * p.ln_g[n]);
+        if (p.ln_stat && p.ln_ksteps == 0) v = s_ln[2 * (r8 * 8 + e) + 1] * (v - s_ln[2 * (r8 * 8 + e)] * p.ln_g[n]);
         o16[e] = (f16)(v + bv);
       }
       if ((p.S & 7) == 0) {
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 
   // LayerNorm fold: mean / rstd of this tile's rows from the producer's per-n-tile partial sums.  Issued first so
   // the loads overlap the main loop; read after the epilogue barrier.
-  __shared__ float s_ln[2 * BM];
+  __shared__ float s_ln[2 * BM + BN];       // {mean, rstd} per tile row, then ln_g of the tile's columns (ln_ksteps > 0)
+  if (p.ln_stat != nullptr && p.ln_ksteps > 0 && tid < BN) s_ln[2 * BM + tid] = n0 + tid < p.N ? p.ln_g[n0 + tid] : 0.f;
   if (p.ln_stat != nullptr && tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     const f32x2* sp = (const f32x2*)p.ln_stat + (size_t)m * p.ln_ntn;
@@ -422,6 +423,21 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     }
   };
 
+  // partial LayerNorm fold (ln_ksteps): rescale the accumulators in registers once the folded K segment has been summed
+  auto rescale_ln = [&]() {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const float gcol = s_ln[2 * BM + wn * C::TN + j * 32 + r];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          acc[i][j][e] = s_ln[2 * row + 1] * (acc[i][j][e] - s_ln[2 * row] * gcol);
+        }
+      }
+  };
+  const int ln_at = p.ln_stat != nullptr ? p.ln_ksteps : 0;     // K-step count after which to rescale (ksplit == 1: kt0 == 0)
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_setup = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
@@ -494,7 +510,10 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #endif
 #pragma unroll
         for (int j = 0; j < KPI; ++j)
-          if (t * KPI + j < nk) compute(cur * KPI + j);
+          if (t * KPI + j < nk) {
+            compute(cur * KPI + j);
+            if (ln_at && t * KPI + j + 1 == ln_at) rescale_ln();
+          }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef SDMI_CLK_PROBE
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
@@ -529,6 +548,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < nk) stage(nxt);
       compute(cur);
+      if (ln_at && t + 1 == ln_at) rescale_ln();
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
@@ -1432,6 +1452,11 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY_W2(128, 128, 2, 4, 3, "c8"), CFG_ENTRY_W2(128, 128, 4, 2, 3, "c8m"), CFG_ENTRY_W2(128, 128, 2, 4, 4, "c8"),
     CFG_ENTRY_W2(128, 64, 4, 2, 4, "c8"),  CFG_ENTRY_W2(64, 128, 2, 4, 4, "c8"),
     // (deeper rings, NS = 6..8, were measured on the weight-streaming M = 128 shapes: no gain over NS = 4)
+    // deeper rings for the 1x1 GEMMs whose A operand streams from beyond L2 (21 MB GeGLU tensor at 64x64): with two
+    // stages in flight a 128x128 step waits ~1.5 us of loaded Infinity-Cache latency per 32 KiB (measured 2050 cycles
+    // per K-step on M=8192,N=320,K=1600 against ~1040 on the L2-resident 3x3 convs)
+    CFG_ENTRY_P(64, 64, 2, 2, 6), CFG_ENTRY_P(128, 64, 2, 2, 6), CFG_ENTRY_P(64, 128, 2, 2, 6), CFG_ENTRY_P(64, 64, 2, 2, 8),
+    CFG_ENTRY_W2(128, 64, 4, 2, 6, "c8"),  CFG_ENTRY_W2(64, 128, 2, 4, 6, "c8"),
     // two K-steps per barrier interval
     CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
     CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),
@@ -1547,7 +1572,9 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1) + a.X0 + a.X1, "gemm: K=%d != ks^2*(C0+C1) + X0+X1", a.K);
   SDMI_REQUIRE(a.cs_hi % 8 == 0 && (a.cs_hi == 0 || !a.outT || a.cs_hi <= a.nt0), "gemm: scaled column range must be a multiple of 8 outside the transposed tail");
   SDMI_REQUIRE(!a.rowstat || (a.ksplit <= 1 && !a.outT), "gemm: row statistics need ksplit == 1 and no transposed tail");
-  SDMI_REQUIRE(!a.ln_stat || (a.ksplit <= 1 && a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && !a.res), "gemm: bad LayerNorm-fold arguments");
+  SDMI_REQUIRE(!a.ln_stat || (a.ksplit <= 1 && a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && (!a.res || a.ln_ksteps > 0)), "gemm: bad LayerNorm-fold arguments");
+  SDMI_REQUIRE(a.ln_ksteps >= 0 && (a.ln_ksteps == 0 || (a.ln_stat && a.ks == 1 && !a.outT && a.ln_ksteps * 64 < a.K && a.ln_ksteps * 64 == a.ln_C)),
+               "gemm: partial LayerNorm fold needs ln_stat, a 1x1 GEMM and ln_ksteps*64 == ln_C < K");
   SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");
   SDMI_REQUIRE(a.ks == 1 || a.ks == 3, "gemm: ks=%d", a.ks);
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");

@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void ln_fold_prep_kernel(const void* w_src, in
 
 // Two consecutive linear maps composed at load time (conv_output o linear_geglu_2, sd/diffusion.py:363,381):
 //   out[n][j] = sum_c A[n][c] * B[c][j]   A: [N][K], B: [K][J], fp32 accumulate, fp16 out with row stride ldo.
-__global__ __launch_bounds__(256) void compose_linear_kernel(const void* A, int a_f32, const void* B, int b_f32, f16* out,
-                                                              int N, int K, int J, int ldo) {
+__global__ __launch_bounds__(256) void compose_linear_kernel(const void* A, int a_f32, const void* B, int b_f32, void* out,
+                                                              int out_f32, int N, int K, int J, int ldo) {
   __shared__ float sa[16][17], sb[16][17];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int n = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
@@ -374,7 +374,10 @@ __global__ __launch_bounds__(256) void compose_linear_kernel(const void* A, int 
     for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
     __syncthreads();
   }
-  if (n < N && j < J) out[(size_t)n * ldo + j] = (f16)acc;
+  if (n < N && j < J) {
+    if (out_f32) ((float*)out)[(size_t)n * ldo + j] = acc;
+    else ((f16*)out)[(size_t)n * ldo + j] = (f16)acc;
+  }
 }
 // bias'[n] = sum_c A[n][c] * b_in[c] + b_out[n]
 __global__ __launch_bounds__(64) void compose_bias_kernel(const void* A, int a_f32, const float* b_in, const float* b_out,
@@ -523,10 +526,10 @@ int sdmi_launch_ln_fold_prep(const void* w_src, int is_f32, const float* gamma, 
   return SDMI_OK;
 }
 
-int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, f16* out, int N, int K, int J, int ldo,
-                               hipStream_t st) {
+int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f32, void* out, int out_f32, int N, int K, int J,
+                               int ldo, hipStream_t st) {
   SDMI_REQUIRE(A && B && out && N > 0 && K > 0 && J > 0 && ldo >= J, "compose_linear: bad arguments");
-  hipLaunchKernelGGL(compose_linear_kernel, dim3((J + 15) / 16, (N + 15) / 16), dim3(256), 0, st, A, a_f32, B, b_f32, out, N, K, J, ldo);
+  hipLaunchKernelGGL(compose_linear_kernel, dim3((J + 15) / 16, (N + 15) / 16), dim3(256), 0, st, A, a_f32, B, b_f32, out, out_f32, N, K, J, ldo);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -71,3 +71,7 @@ if __name__ == "__main__":
             bench(128, 1280, K, ks=3, H=8, splits=(4, 6, 8, 12, 16))
         bench(128, 1280, 5120, splits=(2, 4, 6, 8))
         bench(512, 1280, 11520, ks=3, H=16, splits=(3, 4, 6, 8))
+    elif which == "stream1x1":   # 1x1 GEMMs whose A streams from beyond L2 (attention-block linears at 64x64 / 32x32)
+        for (m_, n_, k_) in ((8192, 320, 1600), (8192, 1280, 320), (8192, 960, 320), (8192, 320, 320), (2048, 640, 3200),
+                          (2048, 640, 640), (2048, 2560, 640), (512, 1280, 1280), (512, 5120, 1280)):
+            bench(m_, n_, k_)
