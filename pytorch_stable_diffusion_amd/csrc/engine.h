@@ -535,7 +535,10 @@ struct Engine {
     }
   }
 
+  static constexpr size_t kThrashBytes = (size_t)64 << 20;
+  char* thrash = nullptr;
   int tune_gemm(const GemmArgs& a0, Plan* best) {
+    if (!thrash && !getenv("SDMI_TUNE_WARM")) TRY(dmalloc(&thrash, kThrashBytes));
     hipEvent_t e0, e1;
     SDMI_CHECK_HIP(hipEventCreate(&e0));
     SDMI_CHECK_HIP(hipEventCreate(&e1));
@@ -554,6 +557,11 @@ struct Engine {
         a.ksplit = ks;
         float us = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
+          // Time every candidate with COLD L2s: in the step a GEMM's activations were just written by another kernel
+          // (other XCDs' L2 / Infinity Cache) and its weights come from HBM, while back-to-back repetitions of one
+          // launch keep both L2-warm and mis-rank the configs (measured: a plan that won warm at 44 us ran 57 us in
+          // the step where the warm-loser ran 45 us).  A 64 MiB fill between repetitions evicts the 8 x 4 MiB L2s.
+          if (thrash) SDMI_CHECK_HIP(hipMemsetAsync(thrash, rep, kThrashBytes, st));
           SDMI_CHECK_HIP(hipEventRecord(e0, st));
           int rc = sdmi_launch_gemm(a, cfg, st);
           if (rc != SDMI_OK) return rc;

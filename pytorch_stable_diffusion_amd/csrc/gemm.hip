@@ -189,21 +189,45 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     }
     }   // chunk
   } else {
-    // transposed tail: 8 consecutive rows (tokens) of one column -> 16 B along the key axis
+    // transposed tail: 8 rows (tokens) of one column -> ONE 16-byte store along the key axis.  With the attention
+    // kernel's quad-permuted key order (vt_pos: quads of a 16-key group stored as q0,q2,q1,q3) the 8 tokens a thread
+    // takes are quads {hf, hf+2} of a group -- adjacent in storage -- instead of two neighbouring quads that land 16 B
+    // apart (two 8-byte stores per item before; the V^T tail of in_proj is store-transaction bound).
     const int Ct = p.N - p.nt0;
+    const bool wide = (p.S & 15) == 0 && (BM & 15) == 0;
     for (int idx = tid; idx < (BM / 8) * BN; idx += NT) {
       const int col = idx % BN, r8 = idx / BN;
-      const int m = m0 + r8 * 8, n = n0 + col;
+      const int n = n0 + col;
+      int rows[8];
+      if (wide && p.tperm) {
+        const int g16 = r8 >> 1, hf = r8 & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rows[e] = g16 * 16 + hf * 4 + e; rows[4 + e] = g16 * 16 + 8 + hf * 4 + e; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rows[e] = r8 * 8 + e;
+      }
+      const int m = m0 + rows[0];
       if (m >= p.M || n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
       f16x8 o16;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = Cs[(r8 * 8 + e) * BN + col];
-        if (p.ln_stat && p.ln_ksteps == 0) v = s_ln[2 * (r8 * 8 + e) + 1] * (v - s_ln[2 * (r8 * 8 + e)] * p.ln_g[n]);
+        float v = Cs[rows[e] * BN + col];
+        if (p.ln_stat && p.ln_ksteps == 0) v = s_ln[2 * rows[e] + 1] * (v - s_ln[2 * rows[e]] * p.ln_g[n]);
         o16[e] = (f16)(v + bv);
       }
-      if ((p.S & 7) == 0) {
+      if (wide && p.tperm) {
+        // rows of a 16-token group never straddle images (S % 16 == 0, m0 % 16 == 0); a group beyond M is skipped whole
+        const int b = m / p.S, s = m - b * p.S;               // s = first token of quad hf of its group
+        f16* row = p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt;
+        if (m0 + rows[7] < p.M) *(f16x8*)(row + vt_pos(s, 1)) = o16;
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (m0 + rows[e] < p.M) row[vt_pos(s - (rows[0] - rows[e]), 1)] = o16[e];
+        }
+      } else if ((p.S & 7) == 0) {
         const int b = m / p.S, s = m - b * p.S;
         f16* row = p.outT + ((size_t)b * Ct + (n - p.nt0)) * p.ldt;
         *(f16x4*)(row + vt_pos(s, p.tperm)) = f16x4{o16[0], o16[1], o16[2], o16[3]};
