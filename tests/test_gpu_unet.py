@@ -206,6 +206,7 @@ def test_plan_cache_makes_second_process_deterministic_and_tune_free(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SDMI_PLAN_CACHE_DIR=str(tmp_path), SDMI_PLAN_FILE=os.devnull, PYTHONPATH=root)
+    env.pop("SDMI_RETUNE", None)          # a table-regeneration run exports it; here the cache must be honoured
     runs = []
     for _ in range(3):
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "_plan_child.py")], cwd=root, env=env,
