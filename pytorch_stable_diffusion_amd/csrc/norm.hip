@@ -166,38 +166,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
 }
 
 // Single-launch GroupNorm for small feature maps: one 512-thread block per (group, image) keeps its whole
-// P x cpg slab in registers (<= MAXP channel pairs per thread), exact two-pass statistics, fixed-order
+// P x cpg slab in registers (<= MAXQ 4-channel quads per thread), exact two-pass statistics, fixed-order
 // block reductions (deterministic).  Replaces stats+apply where the slab fits: one kernel boundary less.
+// Accesses are 4 channels wide (16-B fp32 / 8-B fp16 loads, 8-B stores): the first form moved 2 channels per access
+// (4-byte stores) and spent most of its 6-11 us issuing them.
 constexpr int GNF_NT = 512;
-template <int MAXP>
+template <int MAXQ>
 __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   __shared__ float s_w[2][GNF_NT / 64];
-  const int C = p.C0 + p.C1, cpg = C / 32, hp = cpg / 2;
+  const int C = p.C0 + p.C1, cpg = C / 32, q4 = cpg / 4;
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int total = p.P * hp;
-  f32x2 v[MAXP];
+  const int total = p.P * q4;
+  f32x4 v[MAXQ];
   float s = 0.f;
-  // slot = tid + i*NT walks (pixel, channel pair) incrementally: one integer division per thread instead of one per
-  // slot and phase (the compiler's 32-bit division is ~30 VALU instructions; there were up to 128 per thread)
-  const int px_first = tid / hp, j_first = tid - px_first * hp;
-  const int dpx = GNF_NT / hp, dj = GNF_NT - dpx * hp;
+  // slot = tid + i*NT walks (pixel, channel quad) incrementally: one integer division per thread instead of one per
+  // slot and phase (the compiler's 32-bit division is ~30 VALU instructions)
+  const int px_first = tid / q4, j_first = tid - px_first * q4;
+  const int dpx = GNF_NT / q4, dj = GNF_NT - dpx * q4;
   int px = px_first, j = j_first;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
+  for (int i = 0; i < MAXQ; ++i) {
     const int slot = tid + i * GNF_NT;
-    v[i] = f32x2{0.f, 0.f};
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (slot < total) {
-      const int c = g * cpg + 2 * j;
+      const int c = g * cpg + 4 * j;
       const bool second = c >= p.C0;
       const void* base = second ? p.x1 : p.x0;
       const int cs = second ? p.C1 : p.C0;
       const size_t off = ((size_t)n * p.P + px) * cs + (second ? c - p.C0 : c);
-      if (p.in_f32) v[i] = *(const f32x2*)((const float*)base + off);
-      else { const f16x2 h = *(const f16x2*)((const f16*)base + off); v[i] = f32x2{(float)h[0], (float)h[1]}; }
+      if (p.in_f32) v[i] = *(const f32x4*)((const float*)base + off);
+      else { const f16x4 hv = *(const f16x4*)((const f16*)base + off); v[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
     }
-    s += v[i][0] + v[i][1];
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     px += dpx; j += dj;
-    if (j >= hp) { j -= hp; ++px; }
+    if (j >= q4) { j -= q4; ++px; }
   }
   auto block_sum = [&](float x, int which) {
 #pragma unroll
@@ -213,27 +215,31 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   const float mean = block_sum(s, 0) / cnt;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
+  for (int i = 0; i < MAXQ; ++i) {
     if (tid + i * GNF_NT < total) {
-      const float d0 = v[i][0] - mean, d1 = v[i][1] - mean;
-      q += d0 * d0 + d1 * d1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
     }
   }
   const float rstd = rsqrtf(block_sum(q, 1) / cnt + p.eps);
   px = px_first; j = j_first;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
+  for (int i = 0; i < MAXQ; ++i) {
     const int slot = tid + i * GNF_NT;
     if (slot < total) {
-      const int c = g * cpg + 2 * j;
-      const f32x2 ga = *(const f32x2*)(p.gamma + c), be = *(const f32x2*)(p.beta + c);
-      float y0 = (v[i][0] - mean) * rstd * ga[0] + be[0];
-      float y1 = (v[i][1] - mean) * rstd * ga[1] + be[1];
-      if (p.silu) { y0 = y0 * __builtin_amdgcn_rcpf(1.f + __expf(-y0)); y1 = y1 * __builtin_amdgcn_rcpf(1.f + __expf(-y1)); }
-      *(f16x2*)(p.y + ((size_t)n * p.P + px) * C + c) = f16x2{(f16)y0, (f16)y1};
+      const int c = g * cpg + 4 * j;
+      const f32x4 ga = *(const f32x4*)(p.gamma + c), be = *(const f32x4*)(p.beta + c);
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = (v[i][e] - mean) * rstd * ga[e] + be[e];
+        if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
+        o[e] = (f16)y;
+      }
+      *(f16x4*)(p.y + ((size_t)n * p.P + px) * C + c) = o;
     }
     px += dpx; j += dj;
-    if (j >= hp) { j -= hp; ++px; }
+    if (j >= q4) { j -= q4; ++px; }
   }
 }
 
@@ -317,8 +323,8 @@ int sdmi_gn_nchunk(int P) {
 int sdmi_gn_launches(const GnArgs& a) {
   static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 256;   // measured: 64 blocks cannot pull larger maps fast enough
   const int C = a.C0 + a.C1, cpg = C / 32;
-  const long pairs = ((long)a.P * (cpg / 2) + GNF_NT - 1) / GNF_NT;
-  return (cpg % 2 == 0 && a.C0 % 2 == 0 && a.P <= max_px && pairs <= 24) ? 1 : 2;
+  const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
+  return (cpg % 4 == 0 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
 }
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
@@ -328,10 +334,10 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
   if (sdmi_gn_launches(a) == 1) {
     {
-      const long pairs = ((long)a.P * (C / 64) + GNF_NT - 1) / GNF_NT;
+      const long quads = ((long)a.P * (C / 128) + GNF_NT - 1) / GNF_NT;
       const dim3 grid(32, a.B), block(GNF_NT);
-      if (pairs <= 8) hipLaunchKernelGGL(gn_fused_kernel<8>, grid, block, 0, st, a);
-      else hipLaunchKernelGGL(gn_fused_kernel<24>, grid, block, 0, st, a);
+      if (quads <= 4) hipLaunchKernelGGL(gn_fused_kernel<4>, grid, block, 0, st, a);
+      else hipLaunchKernelGGL(gn_fused_kernel<12>, grid, block, 0, st, a);
       SDMI_CHECK_HIP(hipGetLastError());
       return SDMI_OK;
     }

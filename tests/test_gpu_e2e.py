@@ -217,3 +217,24 @@ def test_native_vae_encoder_vs_reference():
     rel = H.rel_l2(nat(x2, n2).cpu(), torch.from_numpy(g["enc512_out"]))
     G.log_metric(test="vae_enc_native", size=512, rel_l2=rel)
     assert rel < 1.2e-3, f"512x512: rel L2 {rel:.2e}"
+
+
+def test_checkpoint_path_on_gpu_matches_direct_load(models, tmp_path):
+    """SURVEY row f2 end to end on the GPU: a pickled standard checkpoint (the synthetic weights routed backwards through
+    the converter's plan) -> model_loader.preload_models_from_standard_weights (torch.load, convert, four strict loads on
+    the device, as sd/model_loader.py:9-50) -> generate().  Same weights, same plans: the image must be bit-identical to
+    the one from the directly loaded models."""
+    import os
+    from pytorch_stable_diffusion_amd import model_converter, model_loader, pipeline
+    sds = model_loader.synthetic_state_dicts()
+    path = os.path.join(tmp_path, "fake-v1-5.ckpt")
+    torch.save({"state_dict": H.inverse_checkpoint(sds, model_converter.conversion_plan())}, path)
+    del sds
+    loaded = model_loader.preload_models_from_standard_weights(path, DEV)
+    os.remove(path)
+    assert set(loaded) == {"clip", "encoder", "decoder", "diffusion"}
+    kw = dict(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=2,
+              seed=3, device=DEV, tokenizer=StubTokenizer())
+    a = pipeline.generate(models=loaded, **kw)
+    b = pipeline.generate(models=models, **kw)
+    assert a.shape == (512, 512, 3) and np.array_equal(a, b)
