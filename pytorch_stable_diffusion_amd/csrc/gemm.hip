@@ -94,7 +94,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
     // it in this loop).  Phase 2 reads the tile from LDS, adds, converts and stores.
     // Items are taken CH at a time so the epilogue's register footprint stays bounded on the big tiles.
     constexpr int ITEMS = (BM * (BN / 8) + NT - 1) / NT;
-    constexpr int CH = ITEMS < 4 ? ITEMS : (NT >= 1024 ? 2 : 4);    // 1024-thread workgroups: 128 VGPRs per lane
+    constexpr int CH0 = ITEMS < 4 ? ITEMS : (NT >= 1024 ? 2 : 4);   // 1024-thread workgroups: 128 VGPRs per lane
+    constexpr int CH = ITEMS % CH0 == 0 ? CH0 : (ITEMS % 5 == 0 ? 5 : 1);   // BN = 160 tiles: 5 or 10 items per thread
     static_assert(ITEMS % CH == 0, "epilogue chunking");
     const bool fold = p.ln_stat != nullptr && p.ln_ksteps == 0;
 #pragma unroll
@@ -181,7 +182,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float x = (float)o16[e]; rs += x; rq += x * x; }
       }
-      if (p.rowstat) {       // wave-uniform branch; the BN/8 lanes of one row are consecutive and aligned
+      if (p.rowstat && ((BN / 8) & (BN / 8 - 1)) == 0) {   // wave-uniform branch; the BN/8 lanes of one row are consecutive and aligned (power-of-two tiles only)
 #pragma unroll
         for (int o = 1; o < BN / 8; o <<= 1) { rs += __shfl_xor(rs, o); rq += __shfl_xor(rq, o); }
         if (c8 == 0 && idx < BM * (BN / 8) && m < p.M) *(f32x2*)(p.rowstat + ((size_t)m * tiles_n + tn) * 2) = f32x2{rs, rq};
@@ -1481,6 +1482,9 @@ const CfgInfo kCfgs[] = {
     // per K-step on M=8192,N=320,K=1600 against ~1040 on the L2-resident 3x3 convs)
     CFG_ENTRY_P(64, 64, 2, 2, 6), CFG_ENTRY_P(128, 64, 2, 2, 6), CFG_ENTRY_P(64, 128, 2, 2, 6), CFG_ENTRY_P(64, 64, 2, 2, 8),
     CFG_ENTRY_W2(128, 64, 4, 2, 6, "c8"),  CFG_ENTRY_W2(64, 128, 2, 4, 6, "c8"),
+    // 160-wide tiles: N = 320 / 640 / 1280 divide by 160, not by 128 (17 % of a 128-wide tiling of N = 320 multiplies
+    // padding), and 64 m-tiles x 2 n-tiles x split-K 2 is exactly one workgroup per CU at 64x64.  3x3 convs only.
+    CFG_ENTRY_P(128, 160, 4, 1, 3), CFG_ENTRY_P(128, 160, 4, 1, 4), CFG_ENTRY_P(64, 160, 2, 1, 4),
     // two K-steps per barrier interval
     CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
     CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),
@@ -1491,6 +1495,7 @@ const CfgInfo kCfgs[] = {
 const CfgInfo kHaloCfgs[] = {
     CFG_ENTRY_H(128, 128, 2, 2, 3), CFG_ENTRY_H(128, 64, 2, 2, 3), CFG_ENTRY_H(64, 64, 2, 2, 3), CFG_ENTRY_H(64, 128, 2, 2, 3),
     CFG_ENTRY_H(256, 128, 4, 2, 3), CFG_ENTRY_H(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
+    CFG_ENTRY_H(128, 160, 4, 1, 3),
 };
 constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
 bool g_hattr_done[kNumHalo] = {};
@@ -1567,6 +1572,7 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   const CfgInfo& c = cfg_info(cfg);
   if (cfg >= kNumCfgs + kNumHalo) return gn_ok(a, c);
   if (a.gn_partial) return false;               // only the fused kernel normalises the A operand
+  if (c.BN % 64 != 0 && (a.ks != 3 || a.rowstat || a.ln_stat || a.outT)) return false;   // 160-wide tiles: 3x3 convs only
   if (a.outT && (a.nt0 % c.BN) != 0) return false;
   if (cfg >= kNumCfgs) {
     if (!halo_ok(a, c)) return false;
@@ -1617,6 +1623,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   const bool halo = cfg >= kNumCfgs && !gnk;
   const CfgInfo& c = cfg_info(cfg);
   if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
+  SDMI_REQUIRE(c.BN % 64 == 0 || (a.ks == 3 && !a.rowstat && !a.ln_stat && !a.outT), "gemm: config %s (160-wide tile) is not applicable to this GEMM: 3x3 convs only", c.name);
   if (gnk) SDMI_REQUIRE(gn_ok(a, c), "gemm: fused-GroupNorm config %s not applicable to this conv", c.name);
   SDMI_REQUIRE(gnk || !a.gn_partial, "gemm: config %s cannot normalise its A operand", c.name);
   if (a.outT) {

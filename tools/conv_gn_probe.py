@@ -52,10 +52,9 @@ def run(B, H, Cin, Cout, cfg_names, gn, silu=1, splits=(1,), iters=30, X=0):
 if __name__ == "__main__":
     tag = os.environ.get("SDMI_LIB", "default")
     print("lib:", tag)
-    run(2, 64, 320, 320, ["t128x128s3p", "h128x128s3", "g128x128", "g128x128d2", "g128x64", "g128x64d2"], gn=False)
-    run(2, 64, 320, 320, ["g128x128", "g128x128d2", "g128x64d2"], gn=True, silu=1)
-    run(2, 64, 640, 320, ["t128x128s4pc8", "h256x128s3", "g128x128", "g128x128d2"], gn=False, splits=(1, 2))
-    run(2, 32, 640, 640, ["t128x128s3p", "h128x128s4", "g128x128", "g128x128d2"], gn=False, splits=(1, 3))
-    run(2, 32, 640, 640, ["g128x128", "g128x128d2"], gn=True, splits=(1, 3))
-    run(2, 16, 1280, 1280, ["t128x128s3p", "g128x128", "g128x128d2"], gn=False, splits=(6,))
-    run(2, 64, 320, 320, ["t128x128s3p", "g128x128", "g128x128d2"], gn=False, X=320)
+    run(2, 64, 320, 320, ["t128x128s3p", "h128x128s3", "g128x128d2", "t128x160s3p", "t128x160s4p", "h128x160s3"], gn=False, splits=(1, 2))
+    run(2, 64, 640, 320, ["h256x128s3", "g128x128d2", "t128x160s3p", "t128x160s4p", "h128x160s3"], gn=False, splits=(1, 2, 4))
+    run(2, 64, 960, 320, ["h256x128s3", "t128x160s4p", "h128x160s3"], gn=False, splits=(2, 4, 6))
+    run(2, 32, 640, 640, ["t128x128s3p", "h128x128s4", "t128x160s4p", "h128x160s3", "t64x160s4p"], gn=False, splits=(2, 3, 4))
+    run(2, 16, 1280, 1280, ["t128x128s3p", "t128x160s4p", "h128x160s3", "t64x160s4p"], gn=False, splits=(4, 6, 8))
+    run(2, 8, 1280, 1280, ["t64x64s3p2", "t64x128s4p", "t64x160s4p"], gn=False, splits=(6, 8, 12, 16))
