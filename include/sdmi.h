@@ -165,6 +165,12 @@ typedef struct sdmi_gemm_desc {
    * the RAW activations, gn_partial the statistics sdmi_op_gn_stats wrote ([B][gn_nchunk][32][2] fp32), gn_gamma /
    * gn_beta the (c0+c1) affine parameters.  Only the "g..." configs accept it (cfg < 0 picks one); NULL: plain conv. */
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
+  /* act = 2: the epilogue is a row softmax in the log2 domain, out = 2^(v - max) / sum over each 128-column n-tile with
+   * columns >= sm_valid (per tile) masked: one attention head per tile (128-wide configs, fp16 out, full tiles).
+   * img_rows > 0: per-image weights, rows [i*img_rows, (i+1)*img_rows) use w + i*w_img_stride (elements, row stride ldw
+   * or K when 0) and bias / ln_g + i*vec_img_stride.  Together: the cross-attention of sd/attention.py:219-256 with
+   * q_proj / out_proj folded into the per-prompt K / V (two GEMMs). */
+  int act, sm_valid, img_rows, w_img_stride, vec_img_stride, ldw;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */

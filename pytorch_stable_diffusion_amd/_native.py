@@ -35,7 +35,9 @@ class GemmDesc(C.Structure):
                 ("rowstat", C.c_void_p), ("ln_stat", C.c_void_p), ("ln_ntn", C.c_int), ("ln_g", C.c_void_p),
                 ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int),
                 ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
-                ("gn_eps", C.c_float), ("gn_silu", C.c_int)]
+                ("gn_eps", C.c_float), ("gn_silu", C.c_int),
+                ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
+                ("vec_img_stride", C.c_int), ("ldw", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None

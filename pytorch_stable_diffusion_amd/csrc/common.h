@@ -81,7 +81,13 @@ struct GemmArgs {
   int ksplit;
   int ksteps_per;
   int n_major;         // tile order inside a K-slice, set by the launcher (gemm.hip): 1 = consecutive tiles walk m first
-  int act;             // epilogue activation after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170)
+  int act;             // epilogue after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170), 2 row softmax in the
+                       //   log2 domain over the tile's 128 columns, columns >= sm_valid masked (one head of the folded
+                       //   cross-attention per n-tile: BN = 128 configs only, fp16 output)
+  int sm_valid;
+  // per-image weights (the folded cross-attention, engine.h xattn_*): rows [i*img_rows, (i+1)*img_rows) use
+  // w + i*w_img_stride and bias / ln_g + i*vec_img_stride.  img_rows = 0: one weight matrix.  BM must divide img_rows.
+  int img_rows, w_img_stride, vec_img_stride;
   // LayerNorm folded around the GEMM (sd/diffusion.py:317,334,351 feeding 321/339/356):
   //  producer side: rowstat != null -> the epilogue also writes per-row {sum, sum of squares} of the fp16 output
   //    over this n-tile to rowstat[(m*tiles_n + tn)*2] (ksplit == 1, no transposed tail);
@@ -190,4 +196,7 @@ int sdmi_launch_compose_linear(const void* A, int a_f32, const void* B, int b_f3
 int sdmi_launch_compose_bias(const void* A, int a_f32, const float* b_in, const float* b_out, float* out, int N, int K,
                              hipStream_t st);
 int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int cols, int ld, hipStream_t st);
+int sdmi_launch_transpose_scale(const void* src, int is_f32, f16* dst, int R, int Cc, float scale, hipStream_t st);
+int sdmi_launch_xattn_mask(const f16* k, const f16* v, f16* dk, f16* dv, int B, int H, int d, int kv_rows, int n_valid,
+                           hipStream_t st);
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);

@@ -57,6 +57,9 @@ struct AttnW {
   // folded into the first C columns ([gamma (.) Wf | Wo], g, h) for the partial LayerNorm fold (GemmArgs::ln_ksteps).
   ConvW ffn;
   FoldW ffn_f;
+  // Folded cross-attention (Engine::xattn_fold, C >= 640): q_proj transposed and pre-multiplied by log2(e)/sqrt(d), the
+  // left factor of  scores = LN2(s1) (Wq^T K_h^T)
+  f16* wqT = nullptr;
   int C = 0, dh = 0, ctx_idx = 0;
 };
 struct Act {
@@ -183,6 +186,21 @@ struct Engine {
   std::vector<std::string> attn_order;
   f16* ctx16 = nullptr;                // [B][80][768]
   std::vector<f16*> ctxK, ctxVt;       // per attention block: [B*80][C], [B][C][128]
+  // Folded cross-attention.  The context is constant over the denoising loop, so q_proj and out_proj are multiplied INTO
+  // the hoisted K and V once per prompt (sd/attention.py:219-256 regrouped):
+  //   scores_h = LN2(s1) Wq_h^T K_h^T / sqrt(d) = LN2(s1) W1_h^T,   W1_h = K_h Wq_h / sqrt(d)   (128 x C per head and image)
+  //   out      = sum_h P_h V_h Wo_h^T + bo      = P W2^T + bo,      W2[:, h*128 + j] = Wo_h V_h[j]  (C x 1024 per image)
+  // so the block's cross-attention is TWO GEMMs with per-image weights -- [M x C] x [C x 1024] with the softmax over each
+  // head's 77 keys in the epilogue (LayerNorm folded as usual), then [M x 1024] x [1024 x C] + residual -- instead of
+  // q_proj, the attention kernel and out_proj.  Used for the C >= 640 blocks on maps of 64..1024 pixels, a multiple of 64
+  // (SDMI_XATTN_FOLD=0: never).  Measured on one MI355X, same box: 4.39 -> 4.31 ms per step (316 -> 305 launches); the
+  // 320-channel blocks keep the three-kernel form (P is 3.2x wider than q there: 4.32 -> 4.36 ms when folded too), and so
+  // do maps beyond 1024 pixels (48x48 at 768x768: 42 us against 36 us).
+  std::vector<f16*> xfW1, xfW2;        // per attention block (nullptr: not folded): [B][1024][C], [C][B*1024]
+  std::vector<float*> xfG, xfH;        // LayerNorm-fold vectors of W1: [B][1024]
+  f16 *xf_km = nullptr, *xf_vm = nullptr, *xf_vp = nullptr;   // set_context scratch: masked K / V [B*1024][Cmax], plain V
+  float* xf_kq = nullptr;                                      //   and K Wq in fp32 [B*1024][Cmax]
+  static constexpr int kXfCols = kHeads * 128;
   int ctx_batch = 0, ctx_tokens = 0;
   // scratch
   f16* zero = nullptr;
@@ -428,6 +446,14 @@ struct Engine {
     TRY(load_ffn(p, C, &a));
     TRY(load_fold(p + ".attention_1.in_proj", 3 * C, C, a.ln1, nullptr, &a.in_proj_f));
     TRY(load_fold(p + ".attention_2.q_proj", C, C, a.ln2, nullptr, &a.q_f));
+    static const int xf_min_c = getenv("SDMI_XATTN_MINC") ? atoi(getenv("SDMI_XATTN_MINC")) : 640;
+    if (C >= xf_min_c) {
+      const sdmi_tensor_desc* t;
+      TRY(need(p + ".attention_2.q_proj.weight", &t, 2, {C, C}));
+      TRY(dmalloc(&a.wqT, (size_t)C * C * 2));
+      TRY(sdmi_launch_transpose_scale(t->data_dev, t->dtype == SDMI_F32, a.wqT, C, C, q_scale(dh), st));
+      weight_bytes += (int64_t)C * C * 2;
+    }
     a.ctx_idx = (int)attn_order.size();
     attn[p] = a;
     attn_order.push_back(p);
@@ -457,7 +483,7 @@ struct Engine {
   int plan_of(GemmArgs& a, std::map<ShapeKey, Plan>::iterator* out) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 1024 * (a.gn_partial != nullptr),
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 1024 * (a.gn_partial != nullptr) + 2048 * (a.img_rows != 0),
                  a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
@@ -552,7 +578,7 @@ struct Engine {
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
         if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
-        if (ks > 1 && a0.ln_stat) continue;          // the folded epilogue lives in the one-pass path only
+        if (ks > 1 && (a0.ln_stat || a0.img_rows || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
@@ -782,6 +808,31 @@ struct Engine {
   // factor folded into every Q projection feeding `attention()`: softmax(q k^T / sqrt(d)) = 2^(q' k^T) normalised
   static float q_scale(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 
+  // set_context side of the folded cross-attention of block i (see xfW1): W1 = (K masked per head) Wq^T-form with
+  // layernorm_2 folded, W2 = Wo (V masked per head)^T.  Both products run on the MFMA GEMM over the full C (the per-head
+  // masks make the off-head terms exact zeros), ~25 us per block once per prompt.
+  int xattn_fold(int i, const AttnW& w, const Act& ctx) {
+    const int B = ctx.B, C = w.C, R = B * kXfCols;
+    { GemmArgs a = base_args(ctx, nullptr, w.v, kCtxPad, 1, 1, 0); a.out = xf_vp; a.ldc = C; TRY(gemm(a)); }
+    TRY(sdmi_launch_xattn_mask(ctxK[i], xf_vp, xf_km, xf_vm, B, kHeads, w.dh, kCtxPad, ctx_tokens, st));
+    {
+      Act km; km.h = xf_km; km.B = 1; km.H = R; km.W = 1; km.C = C;
+      ConvW wq; wq.w = w.wqT; wq.O = C; wq.I = C; wq.ks = 1;
+      GemmArgs a = base_args(km, nullptr, wq, R, 1, 1, 0);
+      a.out = xf_kq; a.out_f32 = 1; a.ldc = C;
+      TRY(gemm(a));
+    }
+    TRY(sdmi_launch_ln_fold_prep(xf_kq, 1, w.ln2.gamma, w.ln2.beta, nullptr, xfW1[i], xfG[i], xfH[i], R, C, st));
+    {
+      Act wo; wo.h = w.out2.w; wo.B = 1; wo.H = C; wo.W = 1; wo.C = C;
+      ConvW vm; vm.w = xf_vm; vm.O = R; vm.I = C; vm.ks = 1;
+      GemmArgs a = base_args(wo, nullptr, vm, C, 1, 1, 0);
+      a.out = xfW2[i]; a.ldc = R;
+      TRY(gemm(a));
+    }
+    return SDMI_OK;
+  }
+
   // UNET_AttentionBlock (sd/diffusion.py:271-381)
   int attn_block(const AttnW& w, const Act& x, Act* y) {
     if (x.C != w.C) { sdmi_set_error("attn_block: C %d vs %d", x.C, w.C); return SDMI_EINVAL; }
@@ -821,18 +872,43 @@ struct Engine {
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s1));
     { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a, &rs)); }
     // cross-attention (K/V hoisted in set_context)
-    if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
-    TRY(new_act(B, x.H, x.W, C, false, &q2));
-    {
-      GemmArgs a = base_args(rs.ptr ? s1 : u, nullptr, w.q, x.H, x.W, 1, 0);
-      if (rs.ptr) fold_ln(a, w.q_f, rs, C);
-      a.out = q2.h; a.ldc = C;
-      a.cscale = q_scale(w.dh); a.cs_hi = C;
-      TRY(gemm(a));
-    }
-    TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
+    static const bool xfold_on = !(getenv("SDMI_XATTN_FOLD") && atoi(getenv("SDMI_XATTN_FOLD")) == 0);
+    const bool xfold = xfold_on && rs.ptr && S % 64 == 0 && S <= 1024 && (int)xfW1.size() > w.ctx_idx && xfW1[w.ctx_idx] != nullptr;
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s2));
-    { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
+    if (xfold) {
+      // two GEMMs with per-image weights (see xfW1 / xfW2): probabilities, then values x out_proj + residual
+      Act pr;
+      TRY(new_act(B, x.H, x.W, kXfCols, false, &pr));
+      {
+        ConvW w1; w1.w = xfW1[w.ctx_idx]; w1.bias = xfH[w.ctx_idx]; w1.O = kXfCols; w1.I = C; w1.ks = 1;
+        GemmArgs a = base_args(s1, nullptr, w1, x.H, x.W, 1, 0);
+        a.ln_stat = rs.ptr; a.ln_ntn = rs.ntn; a.ln_g = xfG[w.ctx_idx]; a.ln_C = C; a.ln_eps = 1e-5f;
+        a.img_rows = S; a.w_img_stride = kXfCols * C; a.vec_img_stride = kXfCols;
+        a.act = 2; a.sm_valid = ctx_tokens;
+        a.out = pr.h; a.ldc = kXfCols;
+        TRY(gemm(a));
+      }
+      {
+        ConvW w2; w2.w = xfW2[w.ctx_idx]; w2.bias = w.out2.bias; w2.O = C; w2.I = kXfCols; w2.ks = 1;
+        GemmArgs a = base_args(pr, nullptr, w2, x.H, x.W, 1, 0);
+        a.ldw = B * kXfCols; a.img_rows = S; a.w_img_stride = kXfCols; a.vec_img_stride = 0;
+        set_res(a, s1);
+        set_out(a, s2);
+        TRY(gemm(a, &rs));
+      }
+    } else {
+      if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
+      TRY(new_act(B, x.H, x.W, C, false, &q2));
+      {
+        GemmArgs a = base_args(rs.ptr ? s1 : u, nullptr, w.q, x.H, x.W, 1, 0);
+        if (rs.ptr) fold_ln(a, w.q_f, rs, C);
+        a.out = q2.h; a.ldc = C;
+        a.cscale = q_scale(w.dh); a.cs_hi = C;
+        TRY(gemm(a));
+      }
+      TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
+      { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
+    }
     // feed-forward + conv_output + the block's long residual: ONE GEMM over [LN3(s2) | s2] (AttnW::ffn)
     if (!rs.ptr) TRY(layernorm(s2, w.ln3, &u));
     TRY(new_act(B, x.H, x.W, C, true, y));

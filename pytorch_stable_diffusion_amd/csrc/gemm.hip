@@ -76,7 +76,7 @@ __device__ __forceinline__ int vt_pos(int s, int perm) {
 // V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, int m0, int n0, int kz, int tid,
-                                           const float* s_ln = nullptr, int tn = 0, int tiles_n = 1) {
+                                           const float* s_ln = nullptr, int tn = 0, int tiles_n = 1, int vec_off = 0) {
   if (p.ksplit > 1) {
     float* slab = p.slab + (size_t)kz * p.M * p.N;
     for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
@@ -115,8 +115,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) rh[it][e] = (f16)0.f;
       if (ok[it]) {
-        if (p.bias) { b0[it] = *(const f32x4*)(p.bias + n); b1[it] = *(const f32x4*)(p.bias + n + 4); }
-        if (fold) { g0[it] = *(const f32x4*)(p.ln_g + n); g1[it] = *(const f32x4*)(p.ln_g + n + 4); }
+        if (p.bias) { b0[it] = *(const f32x4*)(p.bias + vec_off + n); b1[it] = *(const f32x4*)(p.bias + vec_off + n + 4); }
+        if (fold) { g0[it] = *(const f32x4*)(p.ln_g + vec_off + n); g1[it] = *(const f32x4*)(p.ln_g + vec_off + n + 4); }
         if (p.res) {
           if (p.res_f32) {
             const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
@@ -159,6 +159,28 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         if (p.act == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+        }
+        if constexpr (BN == 128) {
+          if (p.act == 2) {
+            // softmax over this row of the tile (one attention head: the 16 lanes of a row are consecutive and aligned; the
+            // launcher guarantees full tiles, so every lane of the wave is here).  Scores are already in the log2 domain.
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (c8 * 8 + e >= p.sm_valid) v[e] = -INFINITY;
+              mx = fmaxf(mx, v[e]);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float su = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] = __builtin_amdgcn_exp2f(v[e] - mx); su += v[e]; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) su += __shfl_xor(su, o);
+            const float inv = __builtin_amdgcn_rcpf(su);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= inv;
+          }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -210,12 +232,12 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       }
       const int m = m0 + rows[0];
       if (m >= p.M || n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float bv = p.bias ? p.bias[vec_off + n] : 0.f;
       f16x8 o16;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = Cs[rows[e] * BN + col];
-        if (p.ln_stat && p.ln_ksteps == 0) v = s_ln[2 * rows[e] + 1] * (v - s_ln[2 * rows[e]] * p.ln_g[n]);
+        if (p.ln_stat && p.ln_ksteps == 0) v = s_ln[2 * rows[e] + 1] * (v - s_ln[2 * rows[e]] * p.ln_g[vec_off + n]);
         o16[e] = (f16)(v + bv);
       }
       if (wide && p.tperm) {
@@ -296,7 +318,11 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   // LayerNorm fold: mean / rstd of this tile's rows from the producer's per-n-tile partial sums.  Issued first so
   // the loads overlap the main loop; read after the epilogue barrier.
   __shared__ float s_ln[2 * BM + BN];       // {mean, rstd} per tile row, then ln_g of the tile's columns (ln_ksteps > 0)
-  if (p.ln_stat != nullptr && p.ln_ksteps > 0 && tid < BN) s_ln[2 * BM + tid] = n0 + tid < p.N ? p.ln_g[n0 + tid] : 0.f;
+  // per-image operands (folded cross-attention): a tile never straddles images (BM divides img_rows)
+  const int img = p.img_rows ? m0 / p.img_rows : 0;
+  const int vec_off = img * p.vec_img_stride;
+  const f16* w_img = p.w + (size_t)img * p.w_img_stride;
+  if (p.ln_stat != nullptr && p.ln_ksteps > 0 && tid < BN) s_ln[2 * BM + tid] = n0 + tid < p.N ? p.ln_g[vec_off + n0 + tid] : 0.f;
   if (p.ln_stat != nullptr && tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     const f32x2* sp = (const f32x2*)p.ln_stat + (size_t)m * p.ln_ntn;
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const int gch = (pc ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
     const bool ok = n < p.N;
-    b_ptr[i] = ok ? p.w + (size_t)n * p.ldw + (size_t)kt0 * 64 + gch : p.zero + gch;
+    b_ptr[i] = ok ? w_img + (size_t)n * p.ldw + (size_t)kt0 * 64 + gch : p.zero + gch;
     b_inc[i] = ok ? 64 : 0;
   }
 
@@ -603,7 +629,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   const unsigned long long clk_cs = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
 
-  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid, s_ln, tn, tiles_n);
+  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid, s_ln, tn, tiles_n, vec_off);
 #ifdef SDMI_CLK_PROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && blockIdx.x < 2048) {
@@ -1488,6 +1514,9 @@ const CfgInfo kCfgs[] = {
     // two K-steps per barrier interval
     CFG_ENTRY_P2(128, 128, 2, 2, 2, 2), CFG_ENTRY_P2(64, 64, 2, 2, 3, 2), CFG_ENTRY_P2(64, 64, 2, 2, 2, 4),
     CFG_ENTRY_P2(128, 64, 2, 2, 3, 2),  CFG_ENTRY_P2(64, 128, 2, 2, 3, 2),
+    // 32-row tiles, one head (128 columns) wide: the softmax GEMM of the folded cross-attention has only N / 128 = 8
+    // n-tiles and no split-K, so at 16x16 / 8x8 (M = 512 / 128) the m-tile count is all the parallelism there is
+    CFG_ENTRY_P(32, 128, 1, 4, 4), CFG_ENTRY_P(32, 128, 1, 4, 6), CFG_ENTRY(32, 128, 1, 4, 4),
 };
 #define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
   {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
@@ -1574,6 +1603,8 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   if (a.gn_partial) return false;               // only the fused kernel normalises the A operand
   if (c.BN % 64 != 0 && (a.ks != 3 || a.rowstat || a.ln_stat || a.outT)) return false;   // 160-wide tiles: 3x3 convs only
   if (a.outT && (a.nt0 % c.BN) != 0) return false;
+  if (a.act == 2 && (c.BN != 128 || cfg >= kNumCfgs)) return false;                      // softmax epilogue: one head per n-tile
+  if (a.img_rows && (a.img_rows % c.BM != 0 || cfg >= kNumCfgs)) return false;
   if (cfg >= kNumCfgs) {
     if (!halo_ok(a, c)) return false;
     const int TH = c.BM / a.Wo;
@@ -1585,6 +1616,8 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
 
 static int pick_cfg(const GemmArgs& a) {
   // heuristic default (the UNet plan autotunes over all cfgs x split-K instead)
+  if (a.act == 2) return a.img_rows % 128 == 0 ? 1 : 6;            // softmax epilogue: 128-wide tiles (t128x128s3 / t64x128s4)
+  if (a.img_rows % 128 != 0) return 9;                             // per-image weights on a 64-pixel map
   if (a.M <= 64) return 9;                                         // t64x64s4
   if (a.N % 128 != 0 && a.N % 64 == 0 && a.N < 512) return 4;      // t128x64s4
   return 1;                                                        // t128x128s3
@@ -1626,6 +1659,11 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(c.BN % 64 == 0 || (a.ks == 3 && !a.rowstat && !a.ln_stat && !a.outT), "gemm: config %s (160-wide tile) is not applicable to this GEMM: 3x3 convs only", c.name);
   if (gnk) SDMI_REQUIRE(gn_ok(a, c), "gemm: fused-GroupNorm config %s not applicable to this conv", c.name);
   SDMI_REQUIRE(gnk || !a.gn_partial, "gemm: config %s cannot normalise its A operand", c.name);
+  SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && !gnk && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
+                              a.sm_valid > 0 && a.sm_valid <= 128),
+               "gemm: the softmax epilogue needs a BN=128 plain tile, full tiles (M %% BM == 0, N %% 128 == 0), fp16 output, no split-K / residual");
+  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && a.ks == 1 && a.ksplit <= 1),
+               "gemm: per-image weights need BM | img_rows | M, a 1x1 GEMM and no split-K");
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
     SDMI_REQUIRE(a.S > 0 && a.ldt % (a.tperm ? 16 : 8) == 0, "gemm: transposed tail needs S > 0 and ldt a multiple of 8 (16 with the quad-permuted key order)");

@@ -354,6 +354,47 @@ __global__ __launch_bounds__(256) void ln_fold_prep_kernel(const void* w_src, in
   }
 }
 
+// dst[c][r] = fp16(scale * src[r][c]): a Linear weight [R][Cc] stored transposed (contraction over its OUTPUT index; the
+// folded cross-attention multiplies K by Wq from the left, engine.h xattn_fold)
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const void* src, int is_f32, f16* dst, int R, int Cc, float scale) {
+  __shared__ float t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cc) v = is_f32 ? ((const float*)src)[(size_t)r * Cc + c] : (float)((const f16*)src)[(size_t)r * Cc + c];
+    t[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) dst[(size_t)c * R + r] = (f16)(scale * t[tx][i]);
+  }
+}
+
+// Per-head masked copies of the hoisted cross-attention K and V: row (b*H + h)*128 + j of dk / dv is row b*kv_rows + j of
+// k / v with every column outside head h zeroed; keys j >= n_valid (and the padding rows up to 128) are zero rows.
+__global__ __launch_bounds__(256) void xattn_mask_kernel(const f16* k, const f16* v, f16* dk, f16* dv, int H, int d, int kv_rows,
+                                                         int n_valid) {
+  const int row = blockIdx.x;                 // (b*H + h)*128 + j
+  const int j = row & 127, bh = row >> 7, h = bh % H, b = bh / H;
+  const int C = H * d;
+  const bool live = j < n_valid;
+  for (int c8 = threadIdx.x; c8 < C / 8; c8 += 256) {
+    f16x8 zk, zv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { zk[e] = (f16)0.f; zv[e] = (f16)0.f; }
+    const int c = c8 * 8;                       // d is a multiple of 8: a chunk never straddles heads
+    if (live && c / d == h) {
+      zk = *(const f16x8*)(k + ((size_t)b * kv_rows + j) * C + c);
+      zv = *(const f16x8*)(v + ((size_t)b * kv_rows + j) * C + c);
+    }
+    *(f16x8*)(dk + (size_t)row * C + c) = zk;
+    *(f16x8*)(dv + (size_t)row * C + c) = zv;
+  }
+}
+
 // Two consecutive linear maps composed at load time (conv_output o linear_geglu_2, sd/diffusion.py:363,381):
 //   out[n][j] = sum_c A[n][c] * B[c][j]   A: [N][K], B: [K][J], fp32 accumulate, fp16 out with row stride ldo.
 __global__ __launch_bounds__(256) void compose_linear_kernel(const void* A, int a_f32, const void* B, int b_f32, void* out,
@@ -546,6 +587,21 @@ int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int c
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(cast_rows_kernel, dim3(blocks), dim3(256), 0, st, src, is_f32, dst, rows, cols, ld);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_transpose_scale(const void* src, int is_f32, f16* dst, int R, int Cc, float scale, hipStream_t st) {
+  SDMI_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose_scale: bad arguments");
+  hipLaunchKernelGGL(transpose_scale_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, is_f32, dst, R, Cc, scale);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+int sdmi_launch_xattn_mask(const f16* k, const f16* v, f16* dk, f16* dv, int B, int H, int d, int kv_rows, int n_valid,
+                           hipStream_t st) {
+  SDMI_REQUIRE(k && v && dk && dv && B > 0 && H > 0 && d % 8 == 0 && n_valid > 0 && n_valid <= 128 && n_valid <= kv_rows,
+               "xattn_mask: bad arguments");
+  hipLaunchKernelGGL(xattn_mask_kernel, dim3(B * H * 128), dim3(256), 0, st, k, v, dk, dv, H, d, kv_rows, n_valid);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

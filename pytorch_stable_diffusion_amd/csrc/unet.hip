@@ -241,6 +241,8 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
     TRY(u->dmalloc(&u->ctx16, (size_t)batch * kCtxPad * kCtx * 2));
     u->ctxK.clear();
     u->ctxVt.clear();
+    u->xfW1.clear(); u->xfW2.clear(); u->xfG.clear(); u->xfH.clear();
+    int cmax = 0;
     for (const std::string& p : u->attn_order) {
       const AttnW& w = u->attn[p];
       f16 *k, *v;
@@ -249,6 +251,24 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
       SDMI_CHECK_HIP(hipMemsetAsync(v, 0, (size_t)batch * w.C * kCtxVtLd * 2, u->st));
       u->ctxK.push_back(k);
       u->ctxVt.push_back(v);
+      f16 *w1 = nullptr, *w2 = nullptr;
+      float *g = nullptr, *h = nullptr;
+      if (w.wqT) {
+        const size_t rows = (size_t)batch * Engine::kXfCols;
+        TRY(u->dmalloc(&w1, rows * w.C * 2));
+        TRY(u->dmalloc(&w2, rows * w.C * 2));
+        TRY(u->dmalloc(&g, rows * 4));
+        TRY(u->dmalloc(&h, rows * 4));
+        cmax = w.C > cmax ? w.C : cmax;
+      }
+      u->xfW1.push_back(w1); u->xfW2.push_back(w2); u->xfG.push_back(g); u->xfH.push_back(h);
+    }
+    if (cmax) {
+      const size_t rows = (size_t)batch * Engine::kXfCols;
+      TRY(u->dmalloc(&u->xf_km, rows * cmax * 2));
+      TRY(u->dmalloc(&u->xf_vm, rows * cmax * 2));
+      TRY(u->dmalloc(&u->xf_vp, (size_t)batch * kCtxPad * cmax * 2));
+      TRY(u->dmalloc(&u->xf_kq, rows * cmax * 4));
     }
   }
   SDMI_CHECK_HIP(hipMemsetAsync(u->ctx16, 0, (size_t)batch * kCtxPad * kCtx * 2, u->st));
@@ -268,6 +288,7 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
       a.outT = u->ctxVt[i]; a.nt0 = 0; a.S = kCtxPad; a.ldt = kCtxVtLd; a.tperm = 1;
       TRY(u->gemm(a));
     }
+    if (u->xfW1[i]) TRY(u->xattn_fold((int)i, w, c));
   }
   return SDMI_OK;
 }
@@ -441,6 +462,8 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.rowstat = d->rowstat; a.ln_stat = d->ln_stat; a.ln_ntn = d->ln_ntn; a.ln_g = d->ln_g; a.ln_C = d->ln_c; a.ln_eps = d->ln_eps;
   a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta;
   a.gn_eps = d->gn_eps; a.gn_silu = d->gn_silu;
+  a.act = d->act; a.sm_valid = d->sm_valid; a.img_rows = d->img_rows; a.w_img_stride = d->w_img_stride;
+  a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;

@@ -37,14 +37,15 @@ def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
 
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
-          rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0):
+          rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
+          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
     c0 = a0.shape[-1]
     c1 = 0 if a1 is None else a1.shape[-1]
-    Nn = w_packed.shape[0]
-    K = w_packed.shape[1]
+    Nn = w_packed.shape[0] if n_out is None else n_out      # n_out: per-image weights stacked in w_packed
+    K = w_packed.shape[1] if not ldw else ks * ks * (c0 + c1)
     M = B * Ho * Wo
     ncols = Nn if out_t is None else max(nt0, 8)
     out = torch.zeros((M, ncols), dtype=torch.float32 if out_f32 else torch.float16, device=a0.device)
@@ -69,6 +70,7 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.rowstat = 0 if rowstat is None else rowstat.data_ptr()
     if ln_stat is not None:
         d.ln_stat, d.ln_ntn, d.ln_g, d.ln_c, d.ln_eps = ln_stat.data_ptr(), ln_stat.shape[1], ln_g.data_ptr(), ln_c, ln_eps
+    d.act, d.sm_valid, d.img_rows, d.w_img_stride, d.vec_img_stride, d.ldw = act, sm_valid, img_rows, w_img_stride, vec_img_stride, ldw
     N.check(lib.sdmi_op_gemm(C.byref(d), N.cur_stream()), "sdmi_op_gemm")
     torch.cuda.synchronize()
     return (out, out16) if want16 else out

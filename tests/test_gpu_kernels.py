@@ -363,3 +363,70 @@ def test_layernorm_fold_transposed_tail():
         v_ref = ref[:, 2 * Cc:].view(B, S, Cc).permute(0, 2, 1)
         got = G.vt_natural_order(vt.cpu()).double().view(B, Cc, ldt)
         assert (got[:, :, :S] - v_ref).abs().max().item() < 1.2e-2, f"cfg {cfg} (V^T)"
+
+
+@pytest.mark.parametrize("S,Cc", [(64, 640), (256, 1280)])
+def test_folded_cross_attention_two_gemms(S, Cc):
+    """Cross-attention with q_proj / out_proj multiplied into the per-prompt K / V (sd/attention.py:219-256
+    regrouped): GEMM 1 = raw stream x (layernorm_2-folded K_h Wq_h) with the per-head softmax over 77 keys in the
+    epilogue and per-image weights, GEMM 2 = probabilities x (Wo_h V_h) + bias + residual.  Checked against the
+    reference order of operations in fp64 for every 128-wide tile that divides the map."""
+    Bn, Hh, T = 2, 8, 77
+    d = Cc // Hh
+    M = Bn * S
+    g = torch.Generator().manual_seed(S + Cc)
+    x = torch.randn((M, Cc), generator=g) * 1.5 + 0.5
+    x16 = x.half()
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    wq = torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)
+    wo = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    bo = torch.randn((Cc,), generator=g)
+    k = (torch.randn((Bn, T, Cc), generator=g) * 1.5).half()
+    v = torch.randn((Bn, T, Cc), generator=g).half()
+    # reference: LayerNorm -> q_proj -> per-head softmax(q k^T / sqrt(d)) v -> out_proj + bias + residual
+    xn = F.layer_norm(x16.double(), (Cc,), gamma.double(), beta.double(), 1e-5)
+    q = (xn @ wq.double().t()).view(Bn, S, Hh, d).transpose(1, 2)
+    kh = k.double().view(Bn, T, Hh, d).transpose(1, 2)
+    vh = v.double().view(Bn, T, Hh, d).transpose(1, 2)
+    p_ref = torch.softmax(q @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)          # (B, H, S, T)
+    o = (p_ref @ vh).transpose(1, 2).reshape(M, Cc)
+    ref = o @ wo.double().t() + bo.double() + x.double()
+    # folded operands (what Engine::xattn_fold builds once per prompt)
+    qs = math.log2(math.e) / math.sqrt(d)
+    w1 = torch.zeros((Bn, Hh, 128, Cc), dtype=torch.float64)
+    w2 = torch.zeros((Cc, Bn, Hh, 128), dtype=torch.float64)
+    for h in range(Hh):
+        sl = slice(h * d, (h + 1) * d)
+        w1[:, h, :T] = qs * (k.double()[:, :, sl] @ wq.double()[sl])                 # (B, T, C)
+        w2[:, :, h, :T] = torch.einsum("cd,btd->cbt", wo.double()[:, sl], v.double()[:, :, sl])
+    w1f, g1, h1 = G.ln_fold_prep(w1.view(Bn * 1024, Cc).float().to(DEV), gamma.to(DEV), beta.to(DEV), None)
+    w2h = w2.view(Cc, Bn * 1024).half().to(DEV)
+    x16d = x16.to(DEV)
+    xf = x16.float()
+    stat = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=1).view(M, 1, 2).to(DEV)
+    lib = N_.load()
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    n_run = 0
+    for pc in _plain_cfgs():
+        bm, bn = G.gemm_tile(pc)
+        if bn != 128 or S % bm:
+            continue
+        pr = G.igemm(x16d.view(1, M, 1, Cc), w1f, B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=h1, cfg=pc, ln_stat=stat, ln_g=g1, ln_c=Cc,
+                     act=2, sm_valid=T, img_rows=S, w_img_stride=1024 * Cc, vec_img_stride=1024, n_out=1024)
+        got_p = pr.float().cpu().view(Bn, S, Hh, 128).permute(0, 2, 1, 3)
+        assert got_p[..., T:].abs().max().item() == 0.0, names[pc]
+        perr = (got_p[..., :T].double() - p_ref).abs().max().item()
+        assert perr < 4e-3, f"{names[pc]}: probabilities max abs err {perr}"
+        for pc2 in (pc, _plain_cfgs()[(n_run * 5 + 7) % len(_plain_cfgs())]):
+            bm2 = G.gemm_tile(pc2)[0]
+            if S % bm2:
+                continue
+            out = G.igemm(pr.view(1, M, 1, 1024), w2h, B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bo.to(DEV), res=x.to(DEV), out_f32=True,
+                          cfg=pc2, img_rows=S, w_img_stride=1024, ldw=Bn * 1024, n_out=Cc)
+            err = (out.cpu().double() - ref).abs().max().item()
+            rel = ((out.cpu().double() - ref).norm() / ref.norm()).item()
+            assert err < 2e-2 and rel < 1e-3, f"{names[pc]} -> {names[pc2]}: max abs {err}, rel L2 {rel}"
+        n_run += 1
+    assert n_run >= 3
+    G.log_metric(test="xattn_fold", S=S, C=Cc, tiles=n_run)
