@@ -171,6 +171,10 @@ typedef struct sdmi_gemm_desc {
    * or K when 0) and bias / ln_g + i*vec_img_stride.  Together: the cross-attention of sd/attention.py:219-256 with
    * q_proj / out_proj folded into the per-prompt K / V (two GEMMs). */
   int act, sm_valid, img_rows, w_img_stride, vec_img_stride, ldw;
+  /* phase2 = 1: nearest x2 upsample + 3x3 conv (sd/diffusion.py:430-435) as four 2x2 convs on the SOURCE grid, one per
+   * output parity: ks = 2, hs x ws = ho x wo = source size, M = 4*B*hs*ws (rows ordered phase, b, y, x), K = 4*(c0+c1),
+   * w = sdmi_op_pack_ups_phase's [4][N][2][2][C], img_rows = M/4, w_img_stride = N*K; out is the (B, 2hs, 2ws, N) map. */
+  int phase2;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
@@ -187,6 +191,9 @@ int sdmi_op_ln_fold_prep(const void* w_dev, int w_dtype, const float* gamma, con
 
 /* PyTorch OIHW (fp32/fp16) -> packed [o < o_keep][kh][kw][I] fp16. */
 int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream);
+/* OIHW 3x3 weights -> the four phase matrices of sdmi_gemm_desc::phase2: out[4][O][2][2][I] fp16 (taps that land on the same
+ * source pixel after the nearest upsample summed in fp32) */
+int sdmi_op_pack_ups_phase(const void* w_dev, int w_dtype, void* out_dev, int O, int I, void* stream);
 
 /* Flash attention: q [B*Sq][ldq], k [B*k_batch_stride][ldk], vt [(b*H+h)*d+dd][ldvt] (keys along the row in the
  * quad-permuted order sdmi_op_gemm's out_t writes, zero-padded to a multiple of 64), o [B*Sq][ldo]; all fp16.

@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
                 ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
                 ("gn_eps", C.c_float), ("gn_silu", C.c_int),
                 ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
-                ("vec_img_stride", C.c_int), ("ldw", C.c_int)]
+                ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -78,6 +78,7 @@ _SIGNATURES = {
     "sdmi_gemm_num_configs": (C.c_int, []),
     "sdmi_gemm_config_name": (C.c_char_p, [C.c_int]),
     "sdmi_op_pack_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_op_pack_ups_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_op_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -88,6 +88,13 @@ struct GemmArgs {
   // per-image weights (the folded cross-attention, engine.h xattn_*): rows [i*img_rows, (i+1)*img_rows) use
   // w + i*w_img_stride and bias / ln_g + i*vec_img_stride.  img_rows = 0: one weight matrix.  BM must divide img_rows.
   int img_rows, w_img_stride, vec_img_stride;
+  // phase2 = 1: nearest x2 upsample + 3x3 conv (sd/diffusion.py:430-435) as FOUR 2x2 convs on the source grid, one per
+  // output parity (py, px): output pixel (2y+py, 2x+px) only sees source rows {y+py-1, y+py} and columns {x+px-1, x+px},
+  // with the 3x3 taps that land on the same source pixel pre-summed (misc.hip pack_ups_phase).  Rows are
+  // m = phase*(M/4) + (b, y, x) over the SOURCE grid (Hs x Ws = Ho x Wo here), ks = 2, K = 4*(C0+C1), img_rows = M/4
+  // selects the phase's weights, and the epilogue scatters row m to output pixel (b, 2y+py, 2x+px) of the 2Hs x 2Ws map.
+  // 4/9 of the multiplies of the 9-tap form.
+  int phase2;
   // LayerNorm folded around the GEMM (sd/diffusion.py:317,334,351 feeding 321/339/356):
   //  producer side: rowstat != null -> the epilogue also writes per-row {sum, sum of squares} of the fp16 output
   //    over this n-tile to rowstat[(m*tiles_n + tn)*2] (ksplit == 1, no transposed tail);
@@ -199,4 +206,5 @@ int sdmi_launch_cast_rows(const void* src, int is_f32, f16* dst, int rows, int c
 int sdmi_launch_transpose_scale(const void* src, int is_f32, f16* dst, int R, int Cc, float scale, hipStream_t st);
 int sdmi_launch_xattn_mask(const f16* k, const f16* v, f16* dk, f16* dv, int B, int H, int d, int kv_rows, int n_valid,
                            hipStream_t st);
+int sdmi_launch_pack_ups_phase(const void* w, int w_f32, f16* out, int O, int I, hipStream_t st);
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);

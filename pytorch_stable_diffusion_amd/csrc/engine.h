@@ -29,7 +29,10 @@ namespace sdmi {
 
 constexpr int kTime = 1280, kCtx = 768, kHeads = 8, kCtxPad = 80, kCtxVtLd = 128;
 
-struct ConvW { f16* w = nullptr; float* bias = nullptr; int O = 0, I = 0, ks = 0; };
+struct ConvW {
+  f16* w = nullptr; float* bias = nullptr; int O = 0, I = 0, ks = 0;
+  f16* w4 = nullptr;   // Upsample convs only: [4 phases][O][2][2][I] pre-summed taps (GemmArgs::phase2)
+};
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW {
   NormW gn1, gn2;
@@ -465,6 +468,19 @@ struct Engine {
     convs[p] = c;
     return SDMI_OK;
   }
+  // the conv of an Upsample layer (sd/diffusion.py:426-435), additionally as four 2x2 phase convs on the source grid
+  int load_ups_conv(const std::string& p, int C) {
+    TRY(load_plain_conv(p, C, C));
+    return pack_ups_phase(p, &convs[p]);
+  }
+  int pack_ups_phase(const std::string& p, ConvW* c) {
+    const sdmi_tensor_desc* t;
+    TRY(need(p + ".weight", &t, 4, {c->O, c->I, 3, 3}));
+    TRY(dmalloc(&c->w4, (size_t)16 * c->O * c->I * 2));
+    TRY(sdmi_launch_pack_ups_phase(t->data_dev, t->dtype == SDMI_F32, c->w4, c->O, c->I, st));
+    weight_bytes += (int64_t)16 * c->O * c->I * 2;
+    return SDMI_OK;
+  }
 
   // ---- activations ---------------------------------------------------------------------------
   int new_act(int B, int H, int W, int C, bool is_stream, Act* a) {
@@ -578,7 +594,7 @@ struct Engine {
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
         if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
-        if (ks > 1 && (a0.ln_stat || a0.img_rows || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
+        if (ks > 1 && (a0.ln_stat || (a0.img_rows && !a0.phase2) || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
@@ -929,6 +945,20 @@ struct Engine {
     const int Ho = pad ? (Hi - 1) / stride + 1 : (Hi + 1 - 3) / stride + 1;
     const int Wo = pad ? (Wi - 1) / stride + 1 : (Wi + 1 - 3) / stride + 1;
     TRY(new_act(x.B, Ho, Wo, w.O, true, y));
+    // x2 upsample + 3x3 conv as four 2x2 phase convs over the source grid: 4/9 of the multiplies, but 16/9 of the weight
+    // bytes -- used from 512 source pixels up (the 8x8 -> 16x16 conv streams its 29 MB of weights at M = 128 and is
+    // weight-bound).  SDMI_UPS_PHASE=0: never; SDMI_UPS_PHASE_MINROWS moves the threshold.
+    static const bool phase_on = !(getenv("SDMI_UPS_PHASE") && atoi(getenv("SDMI_UPS_PHASE")) == 0);
+    static const int phase_min = getenv("SDMI_UPS_PHASE_MINROWS") ? atoi(getenv("SDMI_UPS_PHASE_MINROWS")) : 512;
+    if (phase_on && ups == 1 && stride == 1 && pad == 1 && w.w4 && x.M() >= phase_min && x.M() % 64 == 0) {
+      ConvW wp = w;
+      wp.w = w.w4; wp.ks = 2;
+      GemmArgs a = base_args(x, nullptr, wp, x.H, x.W, 1, 0);
+      a.img_rows = a.M; a.w_img_stride = w.O * 4 * x.C; a.M *= 4; a.phase2 = 1;
+      set_out(a, *y);
+      TRY(gemm(a));
+      return SDMI_OK;
+    }
     GemmArgs a = base_args(x, nullptr, w, Ho, Wo, stride, ups);
     a.pad = pad;
     set_out(a, *y);

@@ -72,6 +72,16 @@ __device__ __forceinline__ int vt_pos(int s, int perm) {
   return (((u & ~3) | gp) << 2) | (s & 3);
 }
 
+// phase2 GEMMs (GemmArgs::phase2): row m = phase*(M/4) + (b, y, x) on the source grid -> output pixel row of the 2x map
+__device__ __forceinline__ int out_row(const GemmArgs& p, int m) {
+  if (!p.phase2) return m;
+  const int rp = p.M >> 2;
+  const int ph = m / rp, rem = m - ph * rp;
+  const int x = rem % p.Ws, t = rem / p.Ws;
+  const int y = t % p.Hs, b = t / p.Hs;
+  return (b * 2 * p.Hs + 2 * y + (ph >> 1)) * (2 * p.Ws) + 2 * x + (ph & 1);
+}
+
 // Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
 // V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
 template <int BM, int BN, int NT>
@@ -110,6 +120,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       const int row = idx / (BN / 8), c8 = idx % (BN / 8);
       const int m = m0 + row, n = n0 + c8 * 8;
       ok[it] = idx < BM * (BN / 8) && m < p.M && n < p.N;
+      const int mo = ok[it] ? out_row(p, m) : 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { r0[it][e] = 0.f; r1[it][e] = 0.f; b0[it][e] = 0.f; b1[it][e] = 0.f; }
 #pragma unroll
@@ -119,11 +130,11 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         if (fold) { g0[it] = *(const f32x4*)(p.ln_g + vec_off + n); g1[it] = *(const f32x4*)(p.ln_g + vec_off + n + 4); }
         if (p.res) {
           if (p.res_f32) {
-            const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+            const float* rp = (const float*)p.res + (size_t)mo * p.ldr + n;
             r0[it] = *(const f32x4*)rp;
             r1[it] = *(const f32x4*)(rp + 4);
           } else {
-            rh[it] = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
+            rh[it] = *(const f16x8*)((const f16*)p.res + (size_t)mo * p.ldr + n);
           }
         }
       }
@@ -190,16 +201,17 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         f16x8 o16;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o16[e] = (f16)v[e];
+        const int mo = out_row(p, m);
         if (p.out_f32) {
-          float* op = (float*)p.out + (size_t)m * p.ldc + n;
+          float* op = (float*)p.out + (size_t)mo * p.ldc + n;
           f32x4 o0, o1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
           *(f32x4*)op = o0;
           *(f32x4*)(op + 4) = o1;
-          if (p.out16) *(f16x8*)(p.out16 + (size_t)m * p.ldc + n) = o16;
+          if (p.out16) *(f16x8*)(p.out16 + (size_t)mo * p.ldc + n) = o16;
         } else {
-          *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
+          *(f16x8*)((f16*)p.out + (size_t)mo * p.ldc + n) = o16;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float x = (float)o16[e]; rs += x; rq += x * x; }
@@ -359,6 +371,14 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       // plain GEMM (every linear / 1x1 conv: 130 of the 178 launches of a step): output row m IS source pixel m, so
       // the four integer divisions per staged row (~35 VALU instructions each) of the im2col decomposition are skipped
       a_ihb[i] = 0; a_iwb[i] = 0; a_pix0[i] = mm;
+    } else if (p.phase2) {
+      const int rp = p.M >> 2;
+      const int ph = mm / rp, rem = mm - ph * rp;
+      const int x = rem % p.Ws, t = rem / p.Ws;
+      const int y = t % p.Hs, b = t / p.Hs;
+      a_ihb[i] = y + (ph >> 1) - 1;
+      a_iwb[i] = x + (ph & 1) - 1;
+      a_pix0[i] = b * p.Hs * p.Ws;
     } else {
       const int ow = mm % p.Wo, t = mm / p.Wo;
       const int oh = t % p.Ho, b = t / p.Ho;
@@ -389,8 +409,8 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   const int ntaps = p.ks * p.ks;
   auto open_segment = [&]() {
     const bool extra = tap >= ntaps;                 // fused 1x1 skip segment: centre tap of x0 | x1
-    const int kh = extra ? p.pad : ((p.ks == 3) ? tap / 3 : 0);
-    const int kw = extra ? p.pad : ((p.ks == 3) ? tap - (tap / 3) * 3 : 0);
+    const int kh = extra ? p.pad : ((p.ks == 3) ? tap / 3 : (p.ks == 2 ? tap >> 1 : 0));
+    const int kw = extra ? p.pad : ((p.ks == 3) ? tap - (tap / 3) * 3 : (p.ks == 2 ? tap & 1 : 0));
     const int Ca = extra ? p.X0 : p.C0, Cb = extra ? p.X1 : p.C1;
     const bool second = seg_c >= Ca;
     const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
@@ -1388,7 +1408,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   const size_t MN = (size_t)p.M * p.N;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total8; idx += gridDim.x * 256u) {
     const unsigned mq = idx / n8;
-    const int m = (int)mq, n = (int)(idx - mq * n8) * 8;
+    const int ms = (int)mq, n = (int)(idx - mq * n8) * 8;       // ms: slab row
+    const int m = out_row(p, ms);                               // output row (phase2 scatter; identity otherwise)
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -1412,7 +1433,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (z0 + j < p.ksplit) {
-          const float* sp = p.slab + (size_t)(z0 + j) * MN + (size_t)m * p.N + n;
+          const float* sp = p.slab + (size_t)(z0 + j) * MN + (size_t)ms * p.N + n;
           s0[j] = *(const f32x4*)sp;
           s1[j] = *(const f32x4*)(sp + 4);
         }
@@ -1639,7 +1660,10 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.ln_ksteps >= 0 && (a.ln_ksteps == 0 || (a.ln_stat && a.ks == 1 && !a.outT && a.ln_ksteps * 64 < a.K && a.ln_ksteps * 64 == a.ln_C)),
                "gemm: partial LayerNorm fold needs ln_stat, a 1x1 GEMM and ln_ksteps*64 == ln_C < K");
   SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");
-  SDMI_REQUIRE(a.ks == 1 || a.ks == 3, "gemm: ks=%d", a.ks);
+  SDMI_REQUIRE(a.ks == 1 || a.ks == 3 || (a.ks == 2 && a.phase2), "gemm: ks=%d", a.ks);
+  SDMI_REQUIRE(!a.phase2 || (a.ks == 2 && a.M % 4 == 0 && a.img_rows == a.M / 4 && a.M == 4 * (a.M / 4 / (a.Hs * a.Ws)) * a.Hs * a.Ws && a.ups == 0 &&
+                             a.stride == 1 && a.X0 == 0 && !a.outT && !a.rowstat && !a.ln_stat),
+               "gemm: a phase-decomposed x2-upsample conv needs ks = 2, M = 4*B*Hs*Ws, img_rows = M/4 and a plain epilogue");
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");
   SDMI_REQUIRE(a.ldc % 8 == 0 && (!a.res || a.ldr % 8 == 0), "gemm: ldc/ldr must be multiples of 8");
   if (cfg < 0) {
@@ -1662,7 +1686,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && !gnk && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
                               a.sm_valid > 0 && a.sm_valid <= 128),
                "gemm: the softmax epilogue needs a BN=128 plain tile, full tiles (M %% BM == 0, N %% 128 == 0), fp16 output, no split-K / residual");
-  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && a.ks == 1 && a.ksplit <= 1),
+  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && (a.ks == 1 || a.phase2) && (a.ksplit <= 1 || a.phase2)),
                "gemm: per-image weights need BM | img_rows | M, a 1x1 GEMM and no split-K");
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);

@@ -354,6 +354,31 @@ __global__ __launch_bounds__(256) void ln_fold_prep_kernel(const void* w_src, in
   }
 }
 
+// Weights of the phase-decomposed x2-upsample conv (GemmArgs::phase2): OIHW 3x3 -> [4 phases][O][ty][tx][I] fp16.
+// Output parity py sees source rows {y+py-1, y+py}: for py = 0 tap row ty = 0 is kernel row 0 and ty = 1 is rows 1+2 (both
+// land on source row y after the nearest upsample); for py = 1, ty = 0 is rows 0+1 and ty = 1 is row 2.  Same along x.
+// The sums are taken in fp32 and rounded to fp16 once.
+__global__ __launch_bounds__(256) void pack_ups_phase_kernel(const void* w, int w_f32, f16* out, int O, int I) {
+  const size_t total = (size_t)16 * O * I;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int i = (int)(idx % I);
+    size_t t = idx / I;
+    const int tap = (int)(t & 3); t >>= 2;
+    const int o = (int)(t % O);
+    const int ph = (int)(t / O);
+    const int py = ph >> 1, px = ph & 1, ty = tap >> 1, tx = tap & 1;
+    const int y0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), y1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+    const int x0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), x1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int dy = y0; dy <= y1; ++dy)
+      for (int dx = x0; dx <= x1; ++dx) {
+        const size_t src = (((size_t)o * I + i) * 3 + dy) * 3 + dx;
+        acc += w_f32 ? ((const float*)w)[src] : (float)((const f16*)w)[src];
+      }
+    out[idx] = (f16)acc;
+  }
+}
+
 // dst[c][r] = fp16(scale * src[r][c]): a Linear weight [R][Cc] stored transposed (contraction over its OUTPUT index; the
 // folded cross-attention multiplies K by Wq from the left, engine.h xattn_fold)
 __global__ __launch_bounds__(256) void transpose_scale_kernel(const void* src, int is_f32, f16* dst, int R, int Cc, float scale) {
@@ -602,6 +627,15 @@ int sdmi_launch_xattn_mask(const f16* k, const f16* v, f16* dk, f16* dv, int B, 
   SDMI_REQUIRE(k && v && dk && dv && B > 0 && H > 0 && d % 8 == 0 && n_valid > 0 && n_valid <= 128 && n_valid <= kv_rows,
                "xattn_mask: bad arguments");
   hipLaunchKernelGGL(xattn_mask_kernel, dim3(B * H * 128), dim3(256), 0, st, k, v, dk, dv, H, d, kv_rows, n_valid);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+int sdmi_launch_pack_ups_phase(const void* w, int w_f32, f16* out, int O, int I, hipStream_t st) {
+  SDMI_REQUIRE(w && out && O > 0 && I > 0, "pack_ups_phase: bad arguments");
+  size_t total = (size_t)16 * O * I;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_ups_phase_kernel, dim3(blocks), dim3(256), 0, st, w, w_f32, out, O, I);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

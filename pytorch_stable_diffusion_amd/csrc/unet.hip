@@ -98,7 +98,7 @@ int load_op(sdmi_unet* u, const std::string& p, const StageOp& op, bool lenient)
       return u->load_attn(p, op.a, op.b);
     case 3:
       if (lenient && !present(".conv.weight")) return SDMI_OK;
-      return u->load_plain_conv(p + ".conv", op.a, op.a);
+      return u->load_ups_conv(p + ".conv", op.a);
   }
   return SDMI_EINVAL;
 }
@@ -463,7 +463,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta;
   a.gn_eps = d->gn_eps; a.gn_silu = d->gn_silu;
   a.act = d->act; a.sm_valid = d->sm_valid; a.img_rows = d->img_rows; a.w_img_stride = d->w_img_stride;
-  a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw;
+  a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw; a.phase2 = d->phase2;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
@@ -497,6 +497,9 @@ int sdmi_op_ln_fold_prep(const void* w_dev, int w_dtype, const float* gamma, con
   return sdmi_launch_ln_fold_prep(w_dev, w_dtype == SDMI_F32, gamma, beta, bias, (f16*)w_out, g_out, h_out, N, C, (hipStream_t)stream);
 }
 
+int sdmi_op_pack_ups_phase(const void* w_dev, int w_dtype, void* out_dev, int O, int I, void* stream) {
+  return sdmi_launch_pack_ups_phase(w_dev, w_dtype == SDMI_F32, (f16*)out_dev, O, I, (hipStream_t)stream);
+}
 int sdmi_op_pack_conv(const void* w_dev, int w_dtype, void* out_dev, int O, int I, int ks, int o_keep, void* stream) {
   return sdmi_launch_pack_conv(w_dev, w_dtype == SDMI_F32, (f16*)out_dev, O, I, ks, o_keep, (hipStream_t)stream);
 }

@@ -162,6 +162,8 @@ static int vae_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags,
       case 9: {
         ConvW c;
         if ((rc = v->load_conv(p, op.b, op.a, 3, true, &c)) != SDMI_OK) return fail(rc);
+        // the conv after an Upsample (sd/decoder.py:258,283,308): also as four 2x2 phase convs (Engine::conv3)
+        if (i > 0 && ops[i - 1].kind == 3 && (rc = v->pack_ups_phase(p, &c)) != SDMI_OK) return fail(rc);
         v->vconv[(int)i] = c;
         break;
       }

@@ -35,10 +35,20 @@ def pack_conv(w: torch.Tensor, o_keep=None) -> torch.Tensor:
     return out
 
 
+def pack_ups_phase(w: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 cuda tensor -> [4*O][4*I] fp16: the four phase matrices of the x2-upsample conv, stacked"""
+    lib = N.load()
+    O, I = w.shape[0], w.shape[1]
+    out = torch.empty((4 * O, 4 * I), dtype=torch.float16, device=w.device)
+    code = N.SDMI_F32 if w.dtype == torch.float32 else N.SDMI_F16
+    N.check(lib.sdmi_op_pack_ups_phase(N.ptr(w.contiguous()), code, N.ptr(out), O, I, N.cur_stream()), "pack_ups_phase")
+    return out
+
+
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
-          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None):
+          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
@@ -46,13 +56,14 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     c1 = 0 if a1 is None else a1.shape[-1]
     Nn = w_packed.shape[0] if n_out is None else n_out      # n_out: per-image weights stacked in w_packed
     K = w_packed.shape[1] if not ldw else ks * ks * (c0 + c1)
-    M = B * Ho * Wo
+    M = B * Ho * Wo * (4 if phase2 else 1)
     ncols = Nn if out_t is None else max(nt0, 8)
     out = torch.zeros((M, ncols), dtype=torch.float32 if out_f32 else torch.float16, device=a0.device)
     out16 = torch.zeros((M, ncols), dtype=torch.float16, device=a0.device) if (want16 and out_f32) else None
     d.a0 = a0.data_ptr(); d.a1 = 0 if a1 is None else a1.data_ptr()
     d.c0, d.c1, d.hs, d.ws, d.ho, d.wo = c0, c1, Hs, Ws, Ho, Wo
     d.ups, d.stride, d.pad, d.ks = ups, stride, (1 if ks == 3 else 0), ks
+    d.phase2 = phase2
     d.M, d.N, d.K = M, Nn, K
     d.w = w_packed.data_ptr()
     d.bias = 0 if bias is None else bias.data_ptr()

@@ -430,3 +430,33 @@ def test_folded_cross_attention_two_gemms(S, Cc):
         n_run += 1
     assert n_run >= 3
     G.log_metric(test="xattn_fold", S=S, C=Cc, tiles=n_run)
+
+
+@pytest.mark.parametrize("Bn,Hs,Ws,Cin,Cout,ksplit", [(2, 16, 16, 128, 192, 1), (1, 8, 24, 64, 64, 1), (2, 32, 32, 64, 128, 2)])
+def test_upsample_conv_as_four_phase_convs(Bn, Hs, Ws, Cin, Cout, ksplit):
+    """Upsample (sd/diffusion.py:426-435: nearest x2, then 3x3 conv) as four 2x2 convs on the source grid with pre-summed taps:
+    must match the 9-tap conv of the materialised upsampled tensor (fp64) and the library's own 9-tap upsample path."""
+    g = torch.Generator().manual_seed(Hs * Ws + Cin)
+    x = torch.randn((Bn, Hs, Ws, Cin), generator=g).half()
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn((Cout,), generator=g)
+    up = F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref = F.conv2d(up, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    w4 = G.pack_ups_phase(w.to(DEV))
+    nine = G.igemm(x.to(DEV), G.pack_conv(w.to(DEV)), B=Bn, Hs=Hs, Ws=Ws, Ho=2 * Hs, Wo=2 * Ws, ks=3, ups=1, bias=bias.to(DEV), out_f32=True)
+    e9 = (nine.cpu().double() - ref).abs().max().item()
+    rows = Bn * Hs * Ws
+    n_run = 0
+    for pc in _plain_cfgs():
+        bm = G.gemm_tile(pc)[0]
+        if rows % bm:
+            continue
+        out = torch.full((4 * rows, Cout), float("nan"), device=DEV)
+        got = G.igemm(x.to(DEV), w4, B=Bn, Hs=Hs, Ws=Ws, Ho=Hs, Wo=Ws, ks=2, bias=bias.to(DEV), out_f32=True, cfg=pc, ksplit=ksplit,
+                      phase2=1, img_rows=rows, w_img_stride=Cout * 4 * Cin, n_out=Cout)
+        del out
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err < max(2 * e9, 4e-3), f"cfg {pc}: max abs err {err} (9-tap path: {e9})"
+        n_run += 1
+    assert n_run >= 8
+    G.log_metric(test="ups_phase", rows=rows, C=Cin, nine_tap_err=e9)
