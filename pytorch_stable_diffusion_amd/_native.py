@@ -40,6 +40,14 @@ class GemmDesc(C.Structure):
                 ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int)]
 
 
+class B2bDesc(C.Structure):
+    _fields_ = [("a1", C.c_void_p), ("lda1", C.c_int), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("r1", C.c_void_p), ("r1_f32", C.c_int), ("s32", C.c_void_p), ("s16", C.c_void_p),
+                ("w2", C.c_void_p), ("K2", C.c_int), ("h2", C.c_void_p), ("partial", C.c_int), ("cscale", C.c_float),
+                ("r2", C.c_void_p), ("r2_f32", C.c_int), ("out", C.c_void_p), ("out_f32", C.c_int), ("out16", C.c_void_p),
+                ("M", C.c_int), ("eps", C.c_float)]
+
+
 _LIB: Optional[C.CDLL] = None
 
 _SIGNATURES = {
@@ -75,6 +83,7 @@ _SIGNATURES = {
     "sdmi_clip_last_launch_count": (C.c_int, [C.c_void_p]),
     "sdmi_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sdmi_bench_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "sdmi_op_b2b": (C.c_int, [C.POINTER(B2bDesc), C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "sdmi_gemm_num_configs": (C.c_int, []),
     "sdmi_gemm_config_name": (C.c_char_p, [C.c_int]),
     "sdmi_op_pack_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libsdmi.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "unet.hip", "vae.hip", "clip.hip"]
+SOURCES = ["gemm.hip", "b2b.hip", "attention.hip", "norm.hip", "misc.hip", "unet.hip", "vae.hip", "clip.hip"]
 
 
 def _hipcc() -> str:

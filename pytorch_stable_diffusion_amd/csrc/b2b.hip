@@ -1,0 +1,438 @@
+// Back-to-back GEMM for the 320-channel attention blocks (sd/diffusion.py:321-363 at the 64x64 level):
+//
+//     S = A1 W1^T + b1 + R1                      (attention out_proj + residual: sd/diffusion.py:325,343)
+//     Y = f(LayerNorm(S)) W2^T ... + b2 (+ R2)   (the next Linear, with the LayerNorm folded as in gemm.hip)
+//
+// in ONE launch: a workgroup owns 64 full rows (all 320 columns), so the row statistics of S are available in-tile and the
+// fp16 copy of S stays in LDS as the A operand of the second product.  Two forms of the second product:
+//   full fold   (partial = 0):  Y = cscale * (LN0(S) W2'^T + h)                       -- q_proj after out_proj 1
+//   partial fold(partial = 1):  Y = LN0(S) W2a'^T + S W2b^T + h + R2,  W2 = [W2a' | W2b] -- the composed feed-forward
+// with LN0(S) = (S - mean) rstd, W2' = gamma (.) W2 and h = b + W2 beta (sdmi_launch_ln_fold_prep).
+// The K = C GEMMs of these blocks are bound by launch latency plus the fp32 stream's bytes (gemm.hip: ~5 us + bytes / 5 TB/s
+// for 1.7 GFLOP); fusing a pair removes one launch, the re-read of S and -- for the feed-forward, whose input nobody
+// else reads -- the 15.7 MB write of S.
+//
+// Workgroup = 12 waves: 4 MFMA waves (32 rows x 160 columns each: 5 accumulator blocks of 32x32) and 8 DMA waves that
+// stream the 320x64 weight tile (+ the 64x64 A1 tile) of each K-step into a THREE-stage LDS ring with global_load_lds
+// (counted vmcnt: two tiles in flight while one is multiplied -- with two stages every K-step waited a full L2 latency);
+// one s_barrier per K-step.  LDS, all 160 KiB: weight ring 3 x 40 KiB (aliased by the fp32 tile of both epilogues) + 40 KiB
+// that hold the A1 ring during the first product and then S as fp16 in the A-operand layout (five 64-column panels,
+// 16-byte chunks XOR-swizzled on the row).  The LayerNorm is applied to the A fragments in registers on their way from LDS
+// to the MFMA (each lane reads one row: two statistics registers), gamma / beta are in the folded weights and bias; both
+// epilogues are plain bias + residual passes over rows whose residuals were fetched into registers before the product.
+#include "common.h"
+
+namespace {
+
+constexpr int kC = 320, kBM = 64, kNT = 768, kMW = 4, kDW = 8;
+constexpr int kNS = 3;
+constexpr int kAStage = kBM * 128, kWStage = kC * 128;        // 8 KiB, 40 KiB
+constexpr int kRing = kNS * kWStage, kS16 = 5 * kAStage;       // 120 KiB + 40 KiB
+constexpr int kLds = kRing + kS16;
+constexpr int kCsLd = kC + 4;                                  // fp32 tile row stride: +4 floats so the two lane halves of an
+                                                               // accumulator store (rows 4 apart) fall on different LDS banks
+constexpr int kCsBytes = kBM * kCsLd * 4;
+static_assert(kLds <= 160 * 1024, "LDS budget");
+static_assert(kCsBytes + 2 * kBM * 4 <= kRing, "the fp32 epilogue tile and the row statistics alias the weight ring");
+static_assert(kNS * kAStage <= kS16, "the A1 ring aliases the S panels");
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+#ifdef SDMI_B2B_PROBE
+__device__ unsigned long long g_b2b_clk[2][8];   // diagnostic build: shader-clock stamps of workgroup 0 {MFMA wave 0, DMA wave 0}
+#define B2B_STAMP(role, i) do { if (blockIdx.x == 0 && lane == 0 && wave_id == (role ? kMW : 0)) g_b2b_clk[role][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define B2B_STAMP(role, i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * kBM;
+  char* ring = smem;                       // weight ring; Cs + s_ln alias it between the products
+  char* S16 = smem + kRing;                // A1 ring (first product), then S as fp16
+  float* Cs = (float*)smem;
+  float* s_ln = (float*)(smem + kCsBytes);
+  const int n2 = p.K2 / 64;
+
+  // The two roles are separate code paths with their own variables, so the register allocator overlays the MFMA waves'
+  // accumulators with the DMA waves' prefetched residual rows.  Both paths execute the same sequence of barriers.
+  if (wave_id >= kMW) {
+    // =============================== DMA + epilogue waves ===============================
+    const int dw = wave_id - kMW;
+    const int a_row = (dw * 64 + lane) >> 3, a_pc = lane & 7;
+    const f16* a_src = p.a1 + (size_t)(m0 + a_row) * p.lda1 + ((a_pc ^ ((a_row >> 1) & 7)) * 8);
+    // one K-step = (first product only) the 64x64 A1 tile + the 320x64 weight tile, 16 B per lane per instruction
+    auto issue = [&](const f16* w, int ldw, int kofs, bool with_a, int stage) {
+      char* sa = S16 + stage * kAStage;
+      char* sb = ring + stage * kWStage;
+      if (with_a) glds16(a_src + kofs, sa + dw * 1024);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int q = (i * kDW + dw) * 64 + lane;
+        const int row = q >> 3, pc = q & 7;
+        glds16(w + (size_t)row * ldw + kofs + ((pc ^ ((row >> 1) & 7)) * 8), sb + (i * kDW + dw) * 1024);
+      }
+    };
+    // `young`: ordinary loads issued AFTER the first two tiles (the residual rows of the first product, fetched behind the
+    // tiles so the cold first tile is requested as early as possible): they are younger than tiles 0 and 1, so the waits for
+    // those two tiles tolerate them in flight; tile 2 is younger than they are, so from then on the count is the ring's own.
+    auto stream = [&](const f16* w, int ldw, int n, bool a_global, int young) {
+      for (int t = 0; t < n; ++t) {
+        // tile t has landed when at most the newest group (tile t+1) [+ the young loads] is still in flight
+        if (t + 1 < n) {
+          if (a_global) {
+            // `young` is a LOWER bound of the young loads (a stricter wait is always safe, a laxer one never)
+            if (t < 2 && young >= 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          }
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < n) issue(w, ldw, (t + 2) * 64, a_global, (t + 2) % kNS);   // its stage was multiplied in step t-1
+      }
+    };
+    // Epilogue ownership: wave dw takes rows dw + 8 i; lane l < 40 takes two column quads, 4l..4l+3 and 160+4l..163+4l, so
+    // that a 16-byte LDS / global access has a 16-byte lane stride (8 contiguous columns per lane made every ds_read_b128 of
+    // the fp32 tile a 4-way bank conflict: 4 400 cycles for this pass).
+    // Residual rows are fetched into registers BEFORE the product they follow so the epilogue never waits on memory (a
+    // load-use chain per row cost six cold latencies per epilogue: 34 us per launch).  The loads are older than every ring
+    // load of the product, so the counted vmcnt waits of the ring retire them first.
+    const bool own = lane < kC / 8;
+    const int c0 = lane * 4, c1 = kC / 2 + lane * 4;
+    f32x4 rv[8][2], bv[2];
+    auto fetch = [&](const void* res, int is_f32, const float* bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rv[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (res && own) {
+        if (is_f32) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float* rp = (const float*)res + (size_t)(m0 + dw + 8 * i) * kC;
+            rv[i][0] = *(const f32x4*)(rp + c0);
+            rv[i][1] = *(const f32x4*)(rp + c1);
+          }
+        } else {
+          f16x4 t[8][2];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const f16* rp = (const f16*)res + (size_t)(m0 + dw + 8 * i) * kC;
+            t[i][0] = *(const f16x4*)(rp + c0);
+            t[i][1] = *(const f16x4*)(rp + c1);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rv[i][0][e] = (float)t[i][0][e]; rv[i][1][e] = (float)t[i][1][e]; }
+        }
+      }
+      bv[0] = own ? *(const f32x4*)(bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bv[1] = own ? *(const f32x4*)(bias + c1) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- product 1, epilogue 1: S = A1 W1^T + b1 + R1, its fp16 copy into the A-operand panels, row statistics ----
+    B2B_STAMP(1, 0);
+    issue(p.w1, kC, 0, true, 0);
+    issue(p.w1, kC, 64, true, 1);
+    fetch(p.r1, p.r1_f32, p.b1);                         // >= 16 loads (two per row) when there is a residual
+    B2B_STAMP(1, 1);
+    stream(p.w1, kC, kC / 64, true, p.r1 ? 16 : 0);
+    B2B_STAMP(1, 2);
+    __syncthreads();                                     // B1: every ring read retired
+    __syncthreads();                                     // B2: accumulators are in Cs
+    B2B_STAMP(1, 3);
+    // The fp32 tile is read four rows at a time, unconditionally (lanes >= 40 read column 0 and discard it), so the LDS
+    // reads of a batch are in flight together instead of one latency per quad behind a divergent branch.
+    f16x4 o16[8][2];
+    float su[8], sq[8];
+    const int cs0 = own ? c0 : 0, cs1 = own ? c1 : 0;
+#pragma unroll
+    for (int hb = 0; hb < 8; hb += 4) {
+      f32x4 cv[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cv[i][0] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs0);
+        cv[i][1] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs1);
+      }
+      // The epilogue is vector-ALU bound (64 x 320 elements on one CU), so the statistics of the fp16 values use the packed
+      // dot product: sum += x0*1 + x1*1 and sumsq += x0*x0 + x1*x1 are one v_dot2_f32_f16 per element pair each.
+      const f16x2 ones = f16x2{(f16)1.f, (f16)1.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        su[hb + i] = 0.f; sq[hb + i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = own ? cv[i][q][e] + bv[q][e] + rv[hb + i][q][e] : 0.f;
+            cv[i][q][e] = v;
+            o16[hb + i][q][e] = (f16)v;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f16x2 x2 = f16x2{o16[hb + i][q][e], o16[hb + i][q][e + 1]};
+            su[hb + i] = __builtin_amdgcn_fdot2(x2, ones, su[hb + i], false);
+            sq[hb + i] = __builtin_amdgcn_fdot2(x2, x2, sq[hb + i], false);
+          }
+        }
+      }
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const size_t mo = (size_t)(m0 + dw + 8 * (hb + i)) * kC;
+          if (p.s32) { *(f32x4*)(p.s32 + mo + c0) = cv[i][0]; *(f32x4*)(p.s32 + mo + c1) = cv[i][1]; }
+          if (p.s16) { *(f16x4*)(p.s16 + mo + c0) = o16[hb + i][0]; *(f16x4*)(p.s16 + mo + c1) = o16[hb + i][1]; }
+        }
+      }
+    }
+#ifdef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 4);
+#endif
+    // Wave reduction of 8 rows x 2 statistics as ONE butterfly that halves the number of live values per step (4 + 2 + 1
+    // exchanges, then 3 plain steps: 10 ds_bpermute per statistic instead of 48 -- the LDS pipe is shared by the 8 waves).
+    // Afterwards the 8 lanes with equal bits 5..3 hold the totals of row (bit5, bit4, bit3).
+    {
+      const bool hi5 = lane & 32, hi4 = lane & 16, hi3 = lane & 8;
+      float a4[4], b4[4], a2[2], b2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float sa = hi5 ? su[i] : su[i + 4], ka = hi5 ? su[i + 4] : su[i];
+        const float sb = hi5 ? sq[i] : sq[i + 4], kb = hi5 ? sq[i + 4] : sq[i];
+        a4[i] = ka + __shfl_xor(sa, 32);
+        b4[i] = kb + __shfl_xor(sb, 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float sa = hi4 ? a4[i] : a4[i + 2], ka = hi4 ? a4[i + 2] : a4[i];
+        const float sb = hi4 ? b4[i] : b4[i + 2], kb = hi4 ? b4[i + 2] : b4[i];
+        a2[i] = ka + __shfl_xor(sa, 16);
+        b2[i] = kb + __shfl_xor(sb, 16);
+      }
+      float a1, b1;
+      {
+        const float sa = hi3 ? a2[0] : a2[1], ka = hi3 ? a2[1] : a2[0];
+        const float sb = hi3 ? b2[0] : b2[1], kb = hi3 ? b2[1] : b2[0];
+        a1 = ka + __shfl_xor(sa, 8);
+        b1 = kb + __shfl_xor(sb, 8);
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); b1 += __shfl_xor(b1, o); }
+      // statistics of the fp16 values the second product multiplies (as the row-statistics epilogue of gemm.hip)
+      const float mean = a1 * (1.f / kC);
+      float var = b1 * (1.f / kC) - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                      // row i of this wave lives in lanes (i>>2, (i>>1)&1, i&1, x, x, x)
+        const int src = ((i >> 2) << 5) | (((i >> 1) & 1) << 4) | ((i & 1) << 3);
+        su[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), src));
+        sq[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstd), src));
+      }
+    }
+#ifdef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 5);
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = dw + 8 * i;
+      const float mean = su[i], rstd = sq[i];
+      if (lane == 0) { s_ln[2 * row] = mean; s_ln[2 * row + 1] = rstd; }
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          // Full fold: the second product only ever multiplies LN0(S), so the panels hold it (the value the separate
+          // LayerNorm kernel would have written).  Partial fold: they hold S, which the plain half needs; the MFMA waves
+          // normalise the fragments of the folded half on the fly.
+          f16x4 a = o16[i][q];
+          if (!p.partial) {
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (f16)fmaf((float)a[e], rstd, nmr);      // v_fma_mix: (s - mean) rstd
+          }
+          // panel = 64-column group, 16-byte chunk position = chunk ^ key(row): the layout the MFMA waves read A fragments from
+          const int n = q ? c1 : c0;
+          *(f16x4*)(S16 + (n >> 6) * kAStage + row * 128 + (((((n >> 3) & 7) ^ ((row >> 1) & 7))) << 4) + (n & 7) * 2) = a;
+        }
+      }
+    }
+#ifdef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 6);
+#else
+    B2B_STAMP(1, 4);
+#endif
+    fetch(p.r2, p.r2_f32, p.h2);
+    __syncthreads();                                     // B3: S16 and the statistics are written
+    __syncthreads();                                     // B4: the MFMA waves hold the statistics; the ring may be refilled
+#ifdef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 7);
+#else
+    B2B_STAMP(1, 5);
+#endif
+
+    // ---- product 2, epilogue 2: Y = (folded S) W2^T + h2 (+ R2) ----
+    issue(p.w2, p.K2, 0, false, 0);
+    issue(p.w2, p.K2, 64, false, 1);
+    stream(p.w2, p.K2, n2, false, 0);
+#ifndef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 6);
+#endif
+    __syncthreads();                                     // B5
+    __syncthreads();                                     // B6
+#pragma unroll
+    for (int hb = 0; hb < 8; hb += 4) {
+      f32x4 cv[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cv[i][0] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs0);
+        cv[i][1] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs1);
+      }
+      f16x4 o[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = cv[i][q][e] + bv[q][e];
+            if (p.cscale != 0.f) v *= p.cscale;
+            v += rv[hb + i][q][e];
+            cv[i][q][e] = v;
+            o[i][q][e] = (f16)v;
+          }
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const size_t mo = (size_t)(m0 + dw + 8 * (hb + i)) * kC;
+          if (p.out_f32) {
+            *(f32x4*)((float*)p.out + mo + c0) = cv[i][0];
+            *(f32x4*)((float*)p.out + mo + c1) = cv[i][1];
+            if (p.out16) { *(f16x4*)(p.out16 + mo + c0) = o[i][0]; *(f16x4*)(p.out16 + mo + c1) = o[i][1]; }
+          } else {
+            *(f16x4*)((f16*)p.out + mo + c0) = o[i][0];
+            *(f16x4*)((f16*)p.out + mo + c1) = o[i][1];
+          }
+        }
+      }
+    }
+#ifndef SDMI_B2B_PROBE2
+    B2B_STAMP(1, 7);
+#endif
+  } else {
+    // =============================== MFMA waves ===============================
+    const int r = lane & 31, h = lane >> 5;
+    const int key = (r >> 1) & 7;
+    const int rb = wave_id & 1, cg = wave_id >> 1;       // row block, column group (5 blocks of 32 columns)
+    f32x16 acc[5];
+    float rsd = 1.f, nmr = 0.f;                          // rstd and -mean*rstd of the row whose A fragments this lane reads
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    };
+    // norm: the A fragments are LayerNorm-ed on the fly, a = fp16((s - mean) rstd) in fp32 -- the value the separate
+    // LayerNorm kernel would have written; gamma / beta live in the weights / bias (sdmi_launch_ln_fold_prep)
+    auto compute = [&](const char* As, const char* Bs, bool norm) {
+      const char* ap = As + (rb * 32 + r) * 128;
+      const char* bp = Bs + (cg * 160 + r) * 128;
+      f16x8 af[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[s] = *(const f16x8*)(ap + (((2 * s + h) ^ key) << 4));
+      if (norm) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) af[s][e] = (f16)fmaf((float)af[s][e], rsd, nmr);     // v_fma_mix: (s - mean) rstd
+      }
+      // W fragments of column block j+1 are read before the MFMAs of block j (double-buffered in registers), so the LDS
+      // latency hides under the matrix pipe instead of being paid five times per K-step
+      f16x8 bf[2][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bf[0][s] = *(const f16x8*)(bp + (((2 * s + h) ^ key) << 4));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < 4) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[(j + 1) & 1][s] = *(const f16x8*)(bp + (j + 1) * 32 * 128 + (((2 * s + h) ^ key) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bf[j & 1][s], acc[j], 0, 0, 0);
+      }
+    };
+    auto acc_to_lds = [&]() {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          Cs[row * kCsLd + (cg * 5 + j) * 32 + r] = acc[j][e];
+        }
+    };
+
+    zero_acc();
+    B2B_STAMP(0, 0);
+    for (int t = 0; t < kC / 64; ++t) {
+      __builtin_amdgcn_s_barrier();
+      if (t == 0) B2B_STAMP(0, 1);
+      const int st = t % kNS;
+      compute(S16 + st * kAStage, ring + st * kWStage, false);
+    }
+    B2B_STAMP(0, 2);
+    __syncthreads();                                     // B1
+    acc_to_lds();
+    __syncthreads();                                     // B2
+    zero_acc();
+    __syncthreads();                                     // B3
+    rsd = s_ln[2 * (rb * 32 + r) + 1];
+    nmr = -s_ln[2 * (rb * 32 + r)] * rsd;
+    __syncthreads();                                     // B4
+    B2B_STAMP(0, 3);
+    const int n_norm = p.partial ? kC / 64 : 0;          // K-steps whose A fragments are normalised here (partial fold only)
+    for (int t = 0; t < n2; ++t) {
+      __builtin_amdgcn_s_barrier();
+      if (t == 0) B2B_STAMP(0, 4);
+      compute(S16 + (t % 5) * kAStage, ring + (t % kNS) * kWStage, t < n_norm);
+    }
+    B2B_STAMP(0, 5);
+    __syncthreads();                                     // B5
+    acc_to_lds();
+    __syncthreads();                                     // B6
+    B2B_STAMP(0, 6);
+  }
+}
+
+bool g_attr_done = false;
+
+}  // namespace
+
+#ifdef SDMI_B2B_PROBE
+extern "C" int sdmi_dbg_read_b2b(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_b2b_clk), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -5;
+}
+#endif
+
+int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st) {
+  SDMI_REQUIRE(a.M > 0 && a.M % kBM == 0, "b2b: M=%d must be a positive multiple of %d", a.M, kBM);
+  SDMI_REQUIRE(a.K2 == kC || (a.K2 == 2 * kC && a.partial), "b2b: K2=%d (C = %d: K2 = C, or 2C with the partial fold)", a.K2, kC);
+  SDMI_REQUIRE(!a.partial || a.K2 == 2 * kC, "b2b: the partial fold needs K2 = 2C");
+  SDMI_REQUIRE(a.a1 && a.w1 && a.b1 && a.w2 && a.h2 && a.out && a.lda1 >= kC && a.lda1 % 8 == 0, "b2b: null pointer / bad lda");
+  if (!g_attr_done) {
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    g_attr_done = true;
+  }
+  hipLaunchKernelGGL(b2b_kernel, dim3(a.M / kBM), dim3(kNT), kLds, st, a);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}

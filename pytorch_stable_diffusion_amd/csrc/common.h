@@ -118,6 +118,24 @@ struct GemmArgs {
 };
 
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
+
+// Back-to-back GEMM of the 320-channel attention blocks (b2b.hip): S = A1 W1^T + b1 + R1, then the next Linear with the
+// LayerNorm of S folded in, in one launch.  All matrices have 320 columns / output rows.
+struct B2bArgs {
+  const f16* a1; int lda1;        // [M][lda1], K1 = 320
+  const f16* w1; const float* b1; // [320][320], [320]
+  const void* r1; int r1_f32;     // residual of S, [M][320] fp32 or fp16 (or nullptr)
+  float* s32; f16* s16;           // optional copies of S to memory (nullptr: S never leaves the workgroup)
+  const f16* w2; int K2;          // [320][K2]: K2 = 320 (full fold) or 640 = [folded half | plain half] (partial = 1)
+  const float* h2;                // bias of the folded w2: b + W2 beta (sdmi_launch_ln_fold_prep); w2's folded part is gamma (.) W2
+  int partial;
+  float cscale;                   // 0: none
+  const void* r2; int r2_f32;     // residual of Y or nullptr
+  void* out; int out_f32; f16* out16;
+  int M;
+  float eps;
+};
+int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st);
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
 int sdmi_gemm_num_plain_cfgs(void);   // configs [0, n) are igemm_kernel tiles; the rest are halo-reuse conv kernels

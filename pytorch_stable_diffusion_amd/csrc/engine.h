@@ -824,6 +824,27 @@ struct Engine {
   // factor folded into every Q projection feeding `attention()`: softmax(q k^T / sqrt(d)) = 2^(q' k^T) normalised
   static float q_scale(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 
+  // out_proj + residual, then the next Linear with its LayerNorm, as one launch (b2b.hip): C = 320 blocks only
+  int b2b(const Act& a1, const ConvW& w1, const Act& r1, const Act* s_out, const FoldW& f2, int K2, int partial, float cscale,
+          const Act* r2, const Act& y) {
+    B2bArgs t;
+    memset(&t, 0, sizeof(t));
+    t.a1 = a1.h; t.lda1 = a1.C; t.w1 = w1.w; t.b1 = w1.bias;
+    if (r1.f) { t.r1 = r1.f; t.r1_f32 = 1; } else { t.r1 = r1.h; }
+    if (s_out) { t.s32 = s_out->f; t.s16 = s_out->h; }
+    t.w2 = f2.w; t.K2 = K2; t.h2 = f2.h; t.partial = partial; t.cscale = cscale;
+    if (r2) { if (r2->f) { t.r2 = r2->f; t.r2_f32 = 1; } else { t.r2 = r2->h; } }
+    if (y.f) { t.out = y.f; t.out_f32 = 1; t.out16 = y.h; } else { t.out = y.h; }
+    t.M = a1.M(); t.eps = 1e-5f;
+    const double flops = 2.0 * t.M * 320.0 * (320.0 + K2);
+    prof_begin(0, flops);
+    TRY(sdmi_launch_b2b(t, st));
+    prof_end();
+    launches += 1;
+    log_launch("b2b M=%d K2=%d partial=%d flops=%.0f", t.M, K2, partial, flops);
+    return SDMI_OK;
+  }
+
   // set_context side of the folded cross-attention of block i (see xfW1): W1 = (K masked per head) Wq^T-form with
   // layernorm_2 folded, W2 = Wo (V masked per head)^T.  Both products run on the MFMA GEMM over the full C (the per-head
   // masks make the off-head terms exact zeros), ~25 us per block once per prompt.
@@ -886,10 +907,21 @@ struct Engine {
     TRY(new_act(B, x.H, x.W, C, false, &ao));
     TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s1));
-    { GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a, &rs)); }
+    // C = 320 (the 64x64 level): out_proj 1 + q_proj, and out_proj 2 + feed-forward, each as ONE back-to-back launch
+    static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
+    static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
+    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 64 == 0;
+    bool q_done = false;
+    if (use_b2b) {
+      TRY(new_act(B, x.H, x.W, C, false, &q2));
+      TRY(b2b(ao, w.out1, s0, &s1, w.q_f, C, 0, q_scale(w.dh), nullptr, q2));
+      q_done = true;
+    } else {
+      GemmArgs a = base_args(ao, nullptr, w.out1, x.H, x.W, 1, 0); set_res(a, s0); set_out(a, s1); TRY(gemm(a, &rs));
+    }
     // cross-attention (K/V hoisted in set_context)
     static const bool xfold_on = !(getenv("SDMI_XATTN_FOLD") && atoi(getenv("SDMI_XATTN_FOLD")) == 0);
-    const bool xfold = xfold_on && rs.ptr && S % 64 == 0 && S <= 1024 && (int)xfW1.size() > w.ctx_idx && xfW1[w.ctx_idx] != nullptr;
+    const bool xfold = !q_done && xfold_on && rs.ptr && S % 64 == 0 && S <= 1024 && (int)xfW1.size() > w.ctx_idx && xfW1[w.ctx_idx] != nullptr;
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s2));
     if (xfold) {
       // two GEMMs with per-image weights (see xfW1 / xfW2): probabilities, then values x out_proj + residual
@@ -913,9 +945,9 @@ struct Engine {
         TRY(gemm(a, &rs));
       }
     } else {
-      if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
-      TRY(new_act(B, x.H, x.W, C, false, &q2));
-      {
+      if (!q_done) {
+        if (!rs.ptr) TRY(layernorm(s1, w.ln2, &u));
+        TRY(new_act(B, x.H, x.W, C, false, &q2));
         GemmArgs a = base_args(rs.ptr ? s1 : u, nullptr, w.q, x.H, x.W, 1, 0);
         if (rs.ptr) fold_ln(a, w.q_f, rs, C);
         a.out = q2.h; a.ldc = C;
@@ -923,6 +955,12 @@ struct Engine {
         TRY(gemm(a));
       }
       TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
+      if (use_b2b) {
+        // s2 = out_proj 2 + s1 never leaves the workgroup: its only reader is the feed-forward
+        TRY(new_act(B, x.H, x.W, C, true, y));
+        TRY(b2b(ao, w.out2, s1, nullptr, w.ffn_f, 2 * C, 1, 0.f, &x, *y));
+        return SDMI_OK;
+      }
       { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
     }
     // feed-forward + conv_output + the block's long residual: ONE GEMM over [LN3(s2) | s2] (AttnW::ffn)

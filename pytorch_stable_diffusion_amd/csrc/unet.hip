@@ -488,6 +488,34 @@ int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void
   (void)hipEventDestroy(e1);
   return SDMI_OK;
 }
+int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* stream) {
+  if (!d || iters < 1) { sdmi_set_error("op_b2b: bad arguments"); return SDMI_EINVAL; }
+  B2bArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a1 = (const f16*)d->a1; a.lda1 = d->lda1; a.w1 = (const f16*)d->w1; a.b1 = d->b1; a.r1 = d->r1; a.r1_f32 = d->r1_f32;
+  a.s32 = d->s32; a.s16 = (f16*)d->s16; a.w2 = (const f16*)d->w2; a.K2 = d->K2; a.h2 = d->h2; a.partial = d->partial;
+  a.cscale = d->cscale; a.r2 = d->r2; a.r2_f32 = d->r2_f32; a.out = d->out; a.out_f32 = d->out_f32; a.out16 = (f16*)d->out16;
+  a.M = d->M; a.eps = d->eps;
+  hipStream_t st = (hipStream_t)stream;
+  if (!us_per_iter) {
+    for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st));
+    return SDMI_OK;
+  }
+  hipEvent_t e0, e1;
+  SDMI_CHECK_HIP(hipEventCreate(&e0));
+  SDMI_CHECK_HIP(hipEventCreate(&e1));
+  TRY(sdmi_launch_b2b(a, st));
+  SDMI_CHECK_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st));
+  SDMI_CHECK_HIP(hipEventRecord(e1, st));
+  SDMI_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SDMI_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_iter = ms * 1e3f / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return SDMI_OK;
+}
 int sdmi_gemm_num_configs(void) { return sdmi_gemm_num_cfgs(); }
 const char* sdmi_gemm_config_name(int cfg) { return sdmi_gemm_cfg_name(cfg); }
 

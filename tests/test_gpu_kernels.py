@@ -460,3 +460,64 @@ def test_upsample_conv_as_four_phase_convs(Bn, Hs, Ws, Cin, Cout, ksplit):
         n_run += 1
     assert n_run >= 8
     G.log_metric(test="ups_phase", rows=rows, C=Cin, nine_tap_err=e9)
+
+
+@pytest.mark.parametrize("M,partial,stream_f32", [(128, 0, True), (256, 1, True), (192, 1, False), (64, 0, False)])
+def test_back_to_back_gemm(M, partial, stream_f32):
+    """csrc/b2b.hip: out_proj + residual, then LayerNorm -> Linear (q_proj, or the composed feed-forward over [LN(s) | s])
+    in one launch, against the same chain in fp64 (sd/diffusion.py:325-363 for C = 320)."""
+    import ctypes as C
+    Cc = 320
+    g = torch.Generator().manual_seed(M + partial)
+    a1 = torch.randn((M, Cc), generator=g).half()
+    w1 = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    b1 = torch.randn((Cc,), generator=g)
+    r1 = torch.randn((M, Cc), generator=g) * 2 + 1.0
+    r2 = torch.randn((M, Cc), generator=g)
+    if not stream_f32:
+        r1, r2 = r1.half().float(), r2.half().float()
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    w2 = torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)
+    b2 = torch.randn((Cc,), generator=g)
+    wp = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    s_ref = a1.double() @ w1.double().t() + b1.double() + r1.double()
+    ln = F.layer_norm(s_ref, (Cc,), gamma.double(), beta.double(), 1e-5)
+    if partial:
+        ref = ln @ w2.double().t() + s_ref @ wp.double().t() + b2.double() + r2.double()
+    else:
+        ref = 0.25 * (ln @ w2.double().t() + b2.double())
+    wf, _, hf = G.ln_fold_prep(w2.to(DEV), gamma.to(DEV), beta.to(DEV), b2.to(DEV))
+    if partial:
+        wf = torch.cat([wf, wp.to(DEV)], dim=1).contiguous()
+    rdt = torch.float32 if stream_f32 else torch.float16
+    a1d, w1d, b1d, r1d, r2d = a1.to(DEV), w1.to(DEV), b1.to(DEV), r1.to(DEV).to(rdt), r2.to(DEV).to(rdt)
+    s32 = torch.full((M, Cc), float("nan"), device=DEV)
+    s16 = torch.full((M, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    out = torch.full((M, Cc), float("nan"), device=DEV)
+    out16 = torch.full((M, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    d = N_.B2bDesc()
+    d.a1, d.lda1, d.w1, d.b1 = a1d.data_ptr(), Cc, w1d.data_ptr(), b1d.data_ptr()
+    d.r1, d.r1_f32 = r1d.data_ptr(), int(stream_f32)
+    d.s32, d.s16 = (s32.data_ptr() if stream_f32 else 0), s16.data_ptr()
+    d.w2, d.K2, d.h2, d.partial, d.cscale = wf.data_ptr(), (640 if partial else 320), hf.data_ptr(), partial, (0.0 if partial else 0.25)
+    if partial:
+        d.r2, d.r2_f32 = r2d.data_ptr(), int(stream_f32)
+    if partial and stream_f32:
+        d.out, d.out_f32, d.out16 = out.data_ptr(), 1, out16.data_ptr()
+    else:
+        d.out, d.out_f32 = out16.data_ptr(), 0
+    d.M, d.eps = M, 1e-5
+    N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b")
+    torch.cuda.synchronize()
+    es = (s16.float().cpu().double() - s_ref).abs().max().item()
+    assert es < 1.5e-2, f"S (fp16 copy): max abs err {es}"
+    if stream_f32:
+        assert (s32.cpu().double() - s_ref).abs().max().item() < 4e-3
+    got = (out if (partial and stream_f32) else out16.float()).cpu().double()
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert err < 2.5e-2 and rel < 1.5e-3, f"max abs {err}, rel L2 {rel}"
+    if partial and stream_f32:
+        assert torch.equal(out16.cpu(), out.cpu().half())
+    G.log_metric(test="b2b", M=M, partial=partial, stream_f32=stream_f32, rel_l2=rel, max_abs=err)

@@ -18,7 +18,7 @@ import sys
 
 KIND_PAT = {"igemm": "igemm_kernel", "halo": "conv3_halo_kernel", "finalize": "splitk_finalize", "attn": "attn_kernel",
             "gn_fused": "gn_fused_kernel", "gn_stats": "gn_stats_kernel", "gn_apply": "gn_apply_kernel",
-            "layernorm": "layernorm_kernel", "stem": "stem_conv", "final_conv": "final_conv", "xattn": "xattn"}
+            "layernorm": "layernorm_kernel", "stem": "stem_conv", "final_conv": "final_conv", "xattn": "xattn", "b2b": "b2b_kernel"}
 
 
 def read_rows(path):
@@ -75,7 +75,7 @@ def shape_key(kind, kv):
         return f"{kind:8s} M={kv['M']:>5s} N={kv['N']:>5s} K={kv['K']:>5s}" + (f" ks={kv['ks']} s={kv['s']} up={kv['up']} {kv['cfg']} split {kv['split']}" if kind != "finalize" else f" split {kv['split']}")
     if kind == "attn":
         return f"attn     d={kv['d']} Sq={kv['Sq']} Skv={kv['Skv']}"
-    if kind.startswith("gn") or kind == "layernorm":
+    if kind.startswith("gn") or kind in ("layernorm", "b2b"):
         return f"{kind:8s} " + " ".join(f"{k}={v}" for k, v in kv.items())
     return kind
 
@@ -126,7 +126,7 @@ def cmd_pmc(fetch_csv, write_csv, logp, outp):
                         e["algorithmic"] += (N * K * 2 + a_in + out_b) / len(steps)
     fam = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
     for k, e in res.items():
-        f = "igemm" if e["kind"] in ("igemm", "halo", "finalize") else ("attn" if e["kind"] in ("attn", "xattn") else ("norm" if e["kind"].startswith(("gn", "layer")) else "other"))
+        f = "igemm" if e["kind"] in ("igemm", "halo", "finalize", "b2b") else ("attn" if e["kind"] in ("attn", "xattn") else ("norm" if e["kind"].startswith(("gn", "layer")) else "other"))
         fam[f][0] += e["FETCH_SIZE"]; fam[f][1] += e["WRITE_SIZE"]; fam[f][2] += e["launches_per_step"]
         e["hbm_bytes"] = e["FETCH_SIZE"] + e["WRITE_SIZE"]
         e["launches_per_step"] = round(e["launches_per_step"], 2)
@@ -153,7 +153,7 @@ def cmd_mfma(csv_path, logp, outp):
         steps = steps_of(rows)[-8:]
         for step in steps:
             for (kind, kv, _), r in align(step, log):
-                fam = "igemm" if kind in ("igemm", "halo") else kind
+                fam = "igemm" if kind in ("igemm", "halo", "b2b") else kind
                 e = per.setdefault(fam, collections.defaultdict(float))
                 e[counter] += float(r["Counter_Value"]) / len(steps)
                 if counter == "SQ_VALU_MFMA_BUSY_CYCLES":
