@@ -181,8 +181,8 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream);
 /* Back-to-back GEMM of the 320-channel attention blocks (csrc/b2b.hip; sd/diffusion.py:321-363): S = a1 w1^T + b1 + r1, then
  * Y = cscale * (LN0(S) w2'^T + h2) [partial = 0, K2 = 320] or Y = LN0(S) w2a'^T + S w2b^T + h2 + r2 [partial = 1, K2 = 640,
- * w2 = [w2a' | w2b]] with LN0 = LayerNorm without affine (w2' / h2 from sdmi_op_ln_fold_prep).  M % 64 == 0; every matrix
- * has 320 columns.  s32 / s16: optional copies of S.  iters >= 1 launches; us_per_iter (optional) = time per launch. */
+ * w2 = [w2a' | w2b]] with LN0 = LayerNorm without affine (w2' / h2 from sdmi_op_ln_fold_prep); every matrix
+ * has 320 columns (M % 32 == 0).  s32 / s16: optional copies of S.  iters >= 1 launches; us_per_iter (optional) = time per launch. */
 typedef struct sdmi_b2b_desc {
   const void* a1; int lda1;
   const void* w1; const float* b1;
@@ -196,6 +196,7 @@ typedef struct sdmi_b2b_desc {
   void* out; int out_f32; void* out16;
   int M;
   float eps;
+  int bm;          /* rows per workgroup: 32, 64, or 0 = chosen from M */
 } sdmi_b2b_desc;
 int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);

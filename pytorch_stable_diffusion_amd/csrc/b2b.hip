@@ -24,17 +24,25 @@
 
 namespace {
 
-constexpr int kC = 320, kBM = 64, kNT = 768, kMW = 4, kDW = 8;
+constexpr int kC = 320, kDW = 8;
 constexpr int kNS = 3;
-constexpr int kAStage = kBM * 128, kWStage = kC * 128;        // 8 KiB, 40 KiB
-constexpr int kRing = kNS * kWStage, kS16 = 5 * kAStage;       // 120 KiB + 40 KiB
-constexpr int kLds = kRing + kS16;
+constexpr int kWStage = kC * 128;                              // 40 KiB
+constexpr int kRing = kNS * kWStage;                           // 120 KiB
 constexpr int kCsLd = kC + 4;                                  // fp32 tile row stride: +4 floats so the two lane halves of an
                                                                // accumulator store (rows 4 apart) fall on different LDS banks
-constexpr int kCsBytes = kBM * kCsLd * 4;
-static_assert(kLds <= 160 * 1024, "LDS budget");
-static_assert(kCsBytes + 2 * kBM * 4 <= kRing, "the fp32 epilogue tile and the row statistics alias the weight ring");
-static_assert(kNS * kAStage <= kS16, "the A1 ring aliases the S panels");
+// BM rows per workgroup: 64 (4 MFMA waves) or 32 (2 MFMA waves; twice the workgroups -- one per CU at M = 8192 -- for
+// twice the weight traffic out of L2, and half the epilogue per workgroup)
+template <int BM>
+struct B2bCfg {
+  static constexpr int kBM = BM, kMW = BM / 16, kNT = 64 * (kMW + kDW), kNR = BM / kDW;   // kNR: epilogue rows per DMA wave
+  static constexpr int kAStage = BM * 128, kS16 = 5 * kAStage;
+  static constexpr int kLds = kRing + kS16;
+  static constexpr int kCsBytes = BM * kCsLd * 4;
+  static_assert(BM == 32 || BM == 64, "tile height");
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  static_assert(kCsBytes + 2 * BM * 4 <= kRing, "the fp32 epilogue tile and the row statistics alias the weight ring");
+  static_assert(kNS * kAStage <= kS16, "the A1 ring aliases the S panels");
+};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -44,12 +52,14 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 
 #ifdef SDMI_B2B_PROBE
 __device__ unsigned long long g_b2b_clk[2][8];   // diagnostic build: shader-clock stamps of workgroup 0 {MFMA wave 0, DMA wave 0}
-#define B2B_STAMP(role, i) do { if (blockIdx.x == 0 && lane == 0 && wave_id == (role ? kMW : 0)) g_b2b_clk[role][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define B2B_STAMP(role, i) do { if (blockIdx.x == 0 && lane == 0 && wave_id == (role ? Cf::kMW : 0)) g_b2b_clk[role][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define B2B_STAMP(role, i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
+template <class Cf>
+__global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
+  constexpr int kBM = Cf::kBM, kMW = Cf::kMW, kNR = Cf::kNR, kAStage = Cf::kAStage, kCsBytes = Cf::kCsBytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,12 +76,12 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     // =============================== DMA + epilogue waves ===============================
     const int dw = wave_id - kMW;
     const int a_row = (dw * 64 + lane) >> 3, a_pc = lane & 7;
-    const f16* a_src = p.a1 + (size_t)(m0 + a_row) * p.lda1 + ((a_pc ^ ((a_row >> 1) & 7)) * 8);
+    const f16* a_src = p.a1 + (size_t)(m0 + (a_row < kBM ? a_row : 0)) * p.lda1 + ((a_pc ^ ((a_row >> 1) & 7)) * 8);
     // one K-step = (first product only) the 64x64 A1 tile + the 320x64 weight tile, 16 B per lane per instruction
     auto issue = [&](const f16* w, int ldw, int kofs, bool with_a, int stage) {
       char* sa = S16 + stage * kAStage;
       char* sb = ring + stage * kWStage;
-      if (with_a) glds16(a_src + kofs, sa + dw * 1024);
+      if (with_a && dw * 8 < kBM) glds16(a_src + kofs, sa + dw * 1024);      // 8 rows per wave instruction
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         const int q = (i * kDW + dw) * 64 + lane;
@@ -88,8 +98,16 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
         if (t + 1 < n) {
           if (a_global) {
             // `young` is a LOWER bound of the young loads (a stricter wait is always safe, a laxer one never)
-            if (t < 2 && young >= 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            // (waves beyond the A tile's rows issue 5 loads per tile, the others 6: the count is per wave)
+            if (dw * 8 < kBM) {
+              if (t < 2 && young >= 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+              else if (t < 2 && young >= 8) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+              if (t < 2 && young >= 16) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+              else if (t < 2 && young >= 8) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            }
           } else {
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
           }
@@ -108,31 +126,31 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     // load of the product, so the counted vmcnt waits of the ring retire them first.
     const bool own = lane < kC / 8;
     const int c0 = lane * 4, c1 = kC / 2 + lane * 4;
-    f32x4 rv[8][2], bv[2];
+    f32x4 rv[kNR][2], bv[2];
     auto fetch = [&](const void* res, int is_f32, const float* bias) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < kNR; ++i) {
         rv[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         rv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (res && own) {
         if (is_f32) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < kNR; ++i) {
             const float* rp = (const float*)res + (size_t)(m0 + dw + 8 * i) * kC;
             rv[i][0] = *(const f32x4*)(rp + c0);
             rv[i][1] = *(const f32x4*)(rp + c1);
           }
         } else {
-          f16x4 t[8][2];
+          f16x4 t[kNR][2];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < kNR; ++i) {
             const f16* rp = (const f16*)res + (size_t)(m0 + dw + 8 * i) * kC;
             t[i][0] = *(const f16x4*)(rp + c0);
             t[i][1] = *(const f16x4*)(rp + c1);
           }
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < kNR; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { rv[i][0][e] = (float)t[i][0][e]; rv[i][1][e] = (float)t[i][1][e]; }
         }
@@ -145,20 +163,20 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     B2B_STAMP(1, 0);
     issue(p.w1, kC, 0, true, 0);
     issue(p.w1, kC, 64, true, 1);
-    fetch(p.r1, p.r1_f32, p.b1);                         // >= 16 loads (two per row) when there is a residual
+    fetch(p.r1, p.r1_f32, p.b1);                         // >= two loads per row when there is a residual
     B2B_STAMP(1, 1);
-    stream(p.w1, kC, kC / 64, true, p.r1 ? 16 : 0);
+    stream(p.w1, kC, kC / 64, true, p.r1 ? 2 * kNR : 0);
     B2B_STAMP(1, 2);
     __syncthreads();                                     // B1: every ring read retired
     __syncthreads();                                     // B2: accumulators are in Cs
     B2B_STAMP(1, 3);
     // The fp32 tile is read four rows at a time, unconditionally (lanes >= 40 read column 0 and discard it), so the LDS
     // reads of a batch are in flight together instead of one latency per quad behind a divergent branch.
-    f16x4 o16[8][2];
-    float su[8], sq[8];
+    f16x4 o16[kNR][2];
+    float su[kNR], sq[kNR];
     const int cs0 = own ? c0 : 0, cs1 = own ? c1 : 0;
 #pragma unroll
-    for (int hb = 0; hb < 8; hb += 4) {
+    for (int hb = 0; hb < kNR; hb += 4) {
       f32x4 cv[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -204,27 +222,43 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     // Afterwards the 8 lanes with equal bits 5..3 hold the totals of row (bit5, bit4, bit3).
     {
       const bool hi5 = lane & 32, hi4 = lane & 16, hi3 = lane & 8;
-      float a4[4], b4[4], a2[2], b2[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float sa = hi5 ? su[i] : su[i + 4], ka = hi5 ? su[i + 4] : su[i];
-        const float sb = hi5 ? sq[i] : sq[i + 4], kb = hi5 ? sq[i + 4] : sq[i];
-        a4[i] = ka + __shfl_xor(sa, 32);
-        b4[i] = kb + __shfl_xor(sb, 32);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float sa = hi4 ? a4[i] : a4[i + 2], ka = hi4 ? a4[i + 2] : a4[i];
-        const float sb = hi4 ? b4[i] : b4[i + 2], kb = hi4 ? b4[i + 2] : b4[i];
-        a2[i] = ka + __shfl_xor(sa, 16);
-        b2[i] = kb + __shfl_xor(sb, 16);
-      }
       float a1, b1;
-      {
+      if constexpr (kNR == 8) {
+        float a4[4], b4[4], a2[2], b2[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sa = hi5 ? su[i] : su[i + 4], ka = hi5 ? su[i + 4] : su[i];
+          const float sb = hi5 ? sq[i] : sq[i + 4], kb = hi5 ? sq[i + 4] : sq[i];
+          a4[i] = ka + __shfl_xor(sa, 32);
+          b4[i] = kb + __shfl_xor(sb, 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float sa = hi4 ? a4[i] : a4[i + 2], ka = hi4 ? a4[i + 2] : a4[i];
+          const float sb = hi4 ? b4[i] : b4[i + 2], kb = hi4 ? b4[i + 2] : b4[i];
+          a2[i] = ka + __shfl_xor(sa, 16);
+          b2[i] = kb + __shfl_xor(sb, 16);
+        }
         const float sa = hi3 ? a2[0] : a2[1], ka = hi3 ? a2[1] : a2[0];
         const float sb = hi3 ? b2[0] : b2[1], kb = hi3 ? b2[1] : b2[0];
         a1 = ka + __shfl_xor(sa, 8);
         b1 = kb + __shfl_xor(sb, 8);
+      } else {                                             // 4 rows: bits 5, 4 select the row, bit 3 is a plain step
+        float a2[2], b2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float sa = hi5 ? su[i] : su[i + 2], ka = hi5 ? su[i + 2] : su[i];
+          const float sb = hi5 ? sq[i] : sq[i + 2], kb = hi5 ? sq[i + 2] : sq[i];
+          a2[i] = ka + __shfl_xor(sa, 32);
+          b2[i] = kb + __shfl_xor(sb, 32);
+        }
+        const float sa = hi4 ? a2[0] : a2[1], ka = hi4 ? a2[1] : a2[0];
+        const float sb = hi4 ? b2[0] : b2[1], kb = hi4 ? b2[1] : b2[0];
+        a1 = ka + __shfl_xor(sa, 16);
+        b1 = kb + __shfl_xor(sb, 16);
+        a1 += __shfl_xor(a1, 8);
+        b1 += __shfl_xor(b1, 8);
+        (void)hi3;
       }
 #pragma unroll
       for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); b1 += __shfl_xor(b1, o); }
@@ -234,8 +268,8 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
       var = var < 0.f ? 0.f : var;
       const float rstd = rsqrtf(var + p.eps);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                      // row i of this wave lives in lanes (i>>2, (i>>1)&1, i&1, x, x, x)
-        const int src = ((i >> 2) << 5) | (((i >> 1) & 1) << 4) | ((i & 1) << 3);
+      for (int i = 0; i < kNR; ++i) {                    // the lanes holding row i of this wave: its index in lane bits 5.. down
+        const int src = kNR == 8 ? (((i >> 2) << 5) | (((i >> 1) & 1) << 4) | ((i & 1) << 3)) : (((i >> 1) << 5) | ((i & 1) << 4));
         su[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), src));
         sq[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstd), src));
       }
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     B2B_STAMP(1, 5);
 #endif
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < kNR; ++i) {
       const int row = dw + 8 * i;
       const float mean = su[i], rstd = sq[i];
       if (lane == 0) { s_ln[2 * row] = mean; s_ln[2 * row + 1] = rstd; }
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     __syncthreads();                                     // B5
     __syncthreads();                                     // B6
 #pragma unroll
-    for (int hb = 0; hb < 8; hb += 4) {
+    for (int hb = 0; hb < kNR; hb += 4) {
       f32x4 cv[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -332,7 +366,7 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
     // =============================== MFMA waves ===============================
     const int r = lane & 31, h = lane >> 5;
     const int key = (r >> 1) & 7;
-    const int rb = wave_id & 1, cg = wave_id >> 1;       // row block, column group (5 blocks of 32 columns)
+    const int rb = wave_id % (kBM / 32), cg = wave_id / (kBM / 32);   // row block, column group (5 blocks of 32 columns)
     f32x16 acc[5];
     float rsd = 1.f, nmr = 0.f;                          // rstd and -mean*rstd of the row whose A fragments this lane reads
     auto zero_acc = [&]() {
@@ -413,7 +447,18 @@ __global__ __launch_bounds__(kNT) void b2b_kernel(B2bArgs p) {
   }
 }
 
-bool g_attr_done = false;
+template <int BM>
+int launch_b2b(const B2bArgs& a, hipStream_t st) {
+  typedef B2bCfg<BM> Cf;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(b2b_kernel<Cf>, dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
 
 }  // namespace
 
@@ -423,16 +468,14 @@ extern "C" int sdmi_dbg_read_b2b(unsigned long long* host) {
 }
 #endif
 
-int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st) {
-  SDMI_REQUIRE(a.M > 0 && a.M % kBM == 0, "b2b: M=%d must be a positive multiple of %d", a.M, kBM);
+// bm: 32 or 64 rows per workgroup; 0 = 32 while that is at most one workgroup per CU (the 64x64 level: 256 of them; measured
+// 15.6 / 19.1 us against 18.9 / 22.1 us with 64 rows at M = 8192, but 39.5 / 49.7 against 36.1 / 44.3 us at M = 18432)
+int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm) {
+  SDMI_REQUIRE(a.M > 0 && a.M % 32 == 0, "b2b: M=%d must be a positive multiple of 32", a.M);
   SDMI_REQUIRE(a.K2 == kC || (a.K2 == 2 * kC && a.partial), "b2b: K2=%d (C = %d: K2 = C, or 2C with the partial fold)", a.K2, kC);
   SDMI_REQUIRE(!a.partial || a.K2 == 2 * kC, "b2b: the partial fold needs K2 = 2C");
   SDMI_REQUIRE(a.a1 && a.w1 && a.b1 && a.w2 && a.h2 && a.out && a.lda1 >= kC && a.lda1 % 8 == 0, "b2b: null pointer / bad lda");
-  if (!g_attr_done) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    g_attr_done = true;
-  }
-  hipLaunchKernelGGL(b2b_kernel, dim3(a.M / kBM), dim3(kNT), kLds, st, a);
-  SDMI_CHECK_HIP(hipGetLastError());
-  return SDMI_OK;
+  if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256) ? 32 : 64;
+  SDMI_REQUIRE((bm == 32 || bm == 64) && a.M % bm == 0, "b2b: tile height %d does not divide M=%d", bm, a.M);
+  return bm == 32 ? launch_b2b<32>(a, st) : launch_b2b<64>(a, st);
 }

@@ -135,7 +135,7 @@ struct B2bArgs {
   int M;
   float eps;
 };
-int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st);
+int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
 int sdmi_gemm_num_plain_cfgs(void);   // configs [0, n) are igemm_kernel tiles; the rest are halo-reuse conv kernels

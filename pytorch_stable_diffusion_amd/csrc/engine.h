@@ -910,7 +910,7 @@ struct Engine {
     // C = 320 (the 64x64 level): out_proj 1 + q_proj, and out_proj 2 + feed-forward, each as ONE back-to-back launch
     static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
     static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
-    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 64 == 0;
+    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0;
     bool q_done = false;
     if (use_b2b) {
       TRY(new_act(B, x.H, x.W, C, false, &q2));

@@ -498,15 +498,15 @@ int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* str
   a.M = d->M; a.eps = d->eps;
   hipStream_t st = (hipStream_t)stream;
   if (!us_per_iter) {
-    for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st));
+    for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st, d->bm));
     return SDMI_OK;
   }
   hipEvent_t e0, e1;
   SDMI_CHECK_HIP(hipEventCreate(&e0));
   SDMI_CHECK_HIP(hipEventCreate(&e1));
-  TRY(sdmi_launch_b2b(a, st));
+  TRY(sdmi_launch_b2b(a, st, d->bm));
   SDMI_CHECK_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st));
+  for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st, d->bm));
   SDMI_CHECK_HIP(hipEventRecord(e1, st));
   SDMI_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -462,8 +462,9 @@ def test_upsample_conv_as_four_phase_convs(Bn, Hs, Ws, Cin, Cout, ksplit):
     G.log_metric(test="ups_phase", rows=rows, C=Cin, nine_tap_err=e9)
 
 
-@pytest.mark.parametrize("M,partial,stream_f32", [(128, 0, True), (256, 1, True), (192, 1, False), (64, 0, False)])
-def test_back_to_back_gemm(M, partial, stream_f32):
+@pytest.mark.parametrize("M,partial,stream_f32,bm", [(128, 0, True, 64), (256, 1, True, 64), (192, 1, False, 64), (64, 0, False, 64),
+                                                     (96, 0, True, 32), (160, 1, True, 32), (64, 1, False, 32), (32, 0, False, 32)])
+def test_back_to_back_gemm(M, partial, stream_f32, bm):
     """csrc/b2b.hip: out_proj + residual, then LayerNorm -> Linear (q_proj, or the composed feed-forward over [LN(s) | s])
     in one launch, against the same chain in fp64 (sd/diffusion.py:325-363 for C = 320)."""
     import ctypes as C
@@ -507,7 +508,7 @@ def test_back_to_back_gemm(M, partial, stream_f32):
         d.out, d.out_f32, d.out16 = out.data_ptr(), 1, out16.data_ptr()
     else:
         d.out, d.out_f32 = out16.data_ptr(), 0
-    d.M, d.eps = M, 1e-5
+    d.M, d.eps, d.bm = M, 1e-5, bm
     N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b")
     torch.cuda.synchronize()
     es = (s16.float().cpu().double() - s_ref).abs().max().item()

@@ -24,7 +24,7 @@ def main():
     r2 = torch.randn((M, Cc), generator=g).to(dev)
     gamma = (1 + 0.1 * torch.randn((Cc,), generator=g)).to(dev)
     beta = (0.1 * torch.randn((Cc,), generator=g)).to(dev)
-    for K2, partial in ((320, 0), (640, 1)):
+    for K2, partial, bm in ((320, 0, 64), (320, 0, 32), (640, 1, 64), (640, 1, 32)):
         w2 = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).to(dev)
         wf, gf, hf = G.ln_fold_prep(w2, gamma, beta, b1)
         if partial:
@@ -45,11 +45,11 @@ def main():
             d.out, d.out_f32, d.out16 = out.data_ptr(), 1, out16.data_ptr()
         else:
             d.out, d.out_f32 = out16.data_ptr(), 0
-        d.M, d.eps = M, 1e-5
+        d.M, d.eps, d.bm = M, 1e-5, bm
         us = C.c_float(0)
         N.check(lib.sdmi_op_b2b(C.byref(d), 50, C.byref(us), N.cur_stream()), "b2b")
         torch.cuda.synchronize()
-        print(f"b2b M={M} K2={K2} partial={partial}: {us.value:.2f} us / launch (warm, back to back)")
+        print(f"b2b M={M} K2={K2} partial={partial} BM={bm}: {us.value:.2f} us / launch (warm, back to back)")
         if hasattr(lib, "sdmi_dbg_read_b2b"):            # -DSDMI_B2B_PROBE build: shader-clock stamps of workgroup 0
             buf = (C.c_ulonglong * 16)()
             lib.sdmi_dbg_read_b2b.argtypes = [C.POINTER(C.c_ulonglong)]
