@@ -197,6 +197,11 @@ typedef struct sdmi_b2b_desc {
   int M;
   float eps;
   int bm;          /* rows per workgroup: 32, 64, or 0 = chosen from M */
+  /* npass2 = 3 (0 / 1: one pass): the second product is the attention in_proj, w2 = [960][320]: q (x cscale) and k go to
+   * out[M][ldo] (fp16) at columns 0 and 320, v is written transposed to vt[(b*320 + n)*ldt + pos(s)] (m = b*S + s, S % 32 == 0)
+   * in the key order sdmi_op_attention reads.  ldo = 0: 320. */
+  int npass2, ldo;
+  void* vt; int S, ldt;
 } sdmi_b2b_desc;
 int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);

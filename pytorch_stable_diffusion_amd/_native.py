@@ -45,7 +45,8 @@ class B2bDesc(C.Structure):
                 ("r1", C.c_void_p), ("r1_f32", C.c_int), ("s32", C.c_void_p), ("s16", C.c_void_p),
                 ("w2", C.c_void_p), ("K2", C.c_int), ("h2", C.c_void_p), ("partial", C.c_int), ("cscale", C.c_float),
                 ("r2", C.c_void_p), ("r2_f32", C.c_int), ("out", C.c_void_p), ("out_f32", C.c_int), ("out16", C.c_void_p),
-                ("M", C.c_int), ("eps", C.c_float), ("bm", C.c_int)]
+                ("M", C.c_int), ("eps", C.c_float), ("bm", C.c_int),
+                ("npass2", C.c_int), ("ldo", C.c_int), ("vt", C.c_void_p), ("S", C.c_int), ("ldt", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None

@@ -314,50 +314,79 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
     B2B_STAMP(1, 5);
 #endif
 
-    // ---- product 2, epilogue 2: Y = (folded S) W2^T + h2 (+ R2) ----
-    issue(p.w2, p.K2, 0, false, 0);
-    issue(p.w2, p.K2, 64, false, 1);
-    stream(p.w2, p.K2, n2, false, 0);
-#ifndef SDMI_B2B_PROBE2
-    B2B_STAMP(1, 6);
-#endif
-    __syncthreads();                                     // B5
-    __syncthreads();                                     // B6
-#pragma unroll
-    for (int hb = 0; hb < kNR; hb += 4) {
-      f32x4 cv[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        cv[i][0] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs0);
-        cv[i][1] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs1);
+    // ---- product 2, epilogue 2: Y = (folded S) W2^T + h2 (+ R2); npass2 = 3: q | k | v of in_proj, 320 columns per pass ----
+    for (int pass = 0; pass < p.npass2; ++pass) {
+      const f16* w2 = p.w2 + (size_t)pass * kC * p.K2;
+      if (pass > 0) {                                    // (the first pass's bias came with fetch())
+        bv[0] = own ? *(const f32x4*)(p.h2 + pass * kC + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[1] = own ? *(const f32x4*)(p.h2 + pass * kC + c1) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep the ring's counted waits exact
       }
-      f16x4 o[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
+      issue(w2, p.K2, 0, false, 0);
+      issue(w2, p.K2, 64, false, 1);
+      stream(w2, p.K2, n2, false, 0);
+#ifndef SDMI_B2B_PROBE2
+      B2B_STAMP(1, 6);
+#endif
+      __syncthreads();                                   // B5
+      __syncthreads();                                   // B6
+      if (p.vt && pass == 2) {
+        // V pass: transposed store, 8 tokens of one column per 16-byte store along the key axis in the attention kernel's
+        // quad-permuted order (gemm.hip vt_pos: quads of a 16-key group stored as q0,q2,q1,q3 -> quads {hf, hf+2} adjacent)
+        const int b = m0 / p.S, s0 = m0 - b * p.S;        // the tile lies inside one image (S % BM == 0)
+        for (int idx = (wave_id - kMW) * 64 + lane; idx < kC * (kBM / 8); idx += kDW * 64) {
+          const int col = idx % kC, piece = idx / kC;
+          const int g16 = piece >> 1, hf = piece & 1;
+          const float bias = p.h2[2 * kC + col];
+          f16x8 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = cv[i][q][e] + bv[q][e];
-            if (p.cscale != 0.f) v *= p.cscale;
-            v += rv[hb + i][q][e];
-            cv[i][q][e] = v;
-            o[i][q][e] = (f16)v;
+            o[e] = (f16)(Cs[(g16 * 16 + hf * 4 + e) * kCsLd + col] + bias);
+            o[4 + e] = (f16)(Cs[(g16 * 16 + 8 + hf * 4 + e) * kCsLd + col] + bias);
           }
-      if (own) {
+          *(f16x8*)(p.vt + ((size_t)b * kC + col) * p.ldt + s0 + g16 * 16 + hf * 8) = o;
+        }
+      } else {
+        const float cs = (p.npass2 == 1 || pass == 0) ? p.cscale : 0.f;
+        const size_t cofs = (size_t)pass * kC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const size_t mo = (size_t)(m0 + dw + 8 * (hb + i)) * kC;
-          if (p.out_f32) {
-            *(f32x4*)((float*)p.out + mo + c0) = cv[i][0];
-            *(f32x4*)((float*)p.out + mo + c1) = cv[i][1];
-            if (p.out16) { *(f16x4*)(p.out16 + mo + c0) = o[i][0]; *(f16x4*)(p.out16 + mo + c1) = o[i][1]; }
-          } else {
-            *(f16x4*)((f16*)p.out + mo + c0) = o[i][0];
-            *(f16x4*)((f16*)p.out + mo + c1) = o[i][1];
+        for (int hb = 0; hb < kNR; hb += 4) {
+          f32x4 cv[4][2];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cv[i][0] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs0);
+            cv[i][1] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs1);
+          }
+          f16x4 o[4][2];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v = cv[i][q][e] + bv[q][e];
+                if (cs != 0.f) v *= cs;
+                v += rv[hb + i][q][e];
+                cv[i][q][e] = v;
+                o[i][q][e] = (f16)v;
+              }
+          if (own) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const size_t mo = (size_t)(m0 + dw + 8 * (hb + i)) * p.ldo + cofs;
+              if (p.out_f32) {
+                *(f32x4*)((float*)p.out + mo + c0) = cv[i][0];
+                *(f32x4*)((float*)p.out + mo + c1) = cv[i][1];
+                if (p.out16) { *(f16x4*)(p.out16 + mo + c0) = o[i][0]; *(f16x4*)(p.out16 + mo + c1) = o[i][1]; }
+              } else {
+                *(f16x4*)((f16*)p.out + mo + c0) = o[i][0];
+                *(f16x4*)((f16*)p.out + mo + c1) = o[i][1];
+              }
+            }
           }
         }
       }
+      if (pass + 1 < p.npass2) __syncthreads();          // B7: the tile is consumed; the next pass refills the ring under it
     }
 #ifndef SDMI_B2B_PROBE2
     B2B_STAMP(1, 7);
@@ -434,15 +463,19 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
     __syncthreads();                                     // B4
     B2B_STAMP(0, 3);
     const int n_norm = p.partial ? kC / 64 : 0;          // K-steps whose A fragments are normalised here (partial fold only)
-    for (int t = 0; t < n2; ++t) {
-      __builtin_amdgcn_s_barrier();
-      if (t == 0) B2B_STAMP(0, 4);
-      compute(S16 + (t % 5) * kAStage, ring + (t % kNS) * kWStage, t < n_norm);
+    for (int pass = 0; pass < p.npass2; ++pass) {
+      if (pass > 0) zero_acc();
+      for (int t = 0; t < n2; ++t) {
+        __builtin_amdgcn_s_barrier();
+        if (t == 0) B2B_STAMP(0, 4);
+        compute(S16 + (t % 5) * kAStage, ring + (t % kNS) * kWStage, t < n_norm);
+      }
+      B2B_STAMP(0, 5);
+      __syncthreads();                                   // B5
+      acc_to_lds();
+      __syncthreads();                                   // B6
+      if (pass + 1 < p.npass2) __syncthreads();          // B7
     }
-    B2B_STAMP(0, 5);
-    __syncthreads();                                     // B5
-    acc_to_lds();
-    __syncthreads();                                     // B6
     B2B_STAMP(0, 6);
   }
 }
@@ -475,7 +508,12 @@ int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm) {
   SDMI_REQUIRE(a.K2 == kC || (a.K2 == 2 * kC && a.partial), "b2b: K2=%d (C = %d: K2 = C, or 2C with the partial fold)", a.K2, kC);
   SDMI_REQUIRE(!a.partial || a.K2 == 2 * kC, "b2b: the partial fold needs K2 = 2C");
   SDMI_REQUIRE(a.a1 && a.w1 && a.b1 && a.w2 && a.h2 && a.out && a.lda1 >= kC && a.lda1 % 8 == 0, "b2b: null pointer / bad lda");
-  if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256) ? 32 : 64;
+  SDMI_REQUIRE(a.npass2 == 1 || (a.npass2 == 3 && !a.partial && !a.r2 && !a.out_f32 && a.vt && a.S > 0 && a.S % 32 == 0 && a.M % a.S == 0 &&
+                                 a.ldt >= a.S && a.ldt % 8 == 0),
+               "b2b: the three-pass form (q | k | v) needs fp16 outputs, no residual, a V^T target and S %% 32 == 0");
+  SDMI_REQUIRE(a.ldo >= a.npass2 * kC - (a.npass2 == 3 ? kC : 0) && a.ldo % 8 == 0, "b2b: output row stride %d", a.ldo);
+  if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256 || (a.npass2 == 3 && a.S % 64 != 0)) ? 32 : 64;
+  SDMI_REQUIRE(a.npass2 == 1 || a.S % bm == 0, "b2b: a %d-row tile would straddle images of %d tokens", bm, a.S);
   SDMI_REQUIRE((bm == 32 || bm == 64) && a.M % bm == 0, "b2b: tile height %d does not divide M=%d", bm, a.M);
   return bm == 32 ? launch_b2b<32>(a, st) : launch_b2b<64>(a, st);
 }

@@ -134,6 +134,11 @@ struct B2bArgs {
   void* out; int out_f32; f16* out16;
   int M;
   float eps;
+  // npass2 = 3: the second product is in_proj (sd/attention.py:42): w2 = [960][320] folded, three passes of 320 output
+  // columns -- q (x cscale) and k into out[M][ldo] at columns 0 / 320, v transposed into vt[(b*320 + n)*ldt + pos(s)] in the
+  // attention kernel's key order (gemm.hip vt_pos), m = b*S + s.  npass2 = 1: one pass, out[M][ldo].
+  int npass2, ldo;
+  f16* vt; int S, ldt;
 };
 int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M
 int sdmi_gemm_num_cfgs();

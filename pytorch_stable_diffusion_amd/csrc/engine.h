@@ -835,13 +835,31 @@ struct Engine {
     t.w2 = f2.w; t.K2 = K2; t.h2 = f2.h; t.partial = partial; t.cscale = cscale;
     if (r2) { if (r2->f) { t.r2 = r2->f; t.r2_f32 = 1; } else { t.r2 = r2->h; } }
     if (y.f) { t.out = y.f; t.out_f32 = 1; t.out16 = y.h; } else { t.out = y.h; }
-    t.M = a1.M(); t.eps = 1e-5f;
+    t.M = a1.M(); t.eps = 1e-5f; t.npass2 = 1; t.ldo = 320;
     const double flops = 2.0 * t.M * 320.0 * (320.0 + K2);
     prof_begin(0, flops);
     TRY(sdmi_launch_b2b(t, st));
     prof_end();
     launches += 1;
     log_launch("b2b M=%d K2=%d partial=%d flops=%.0f", t.M, K2, partial, flops);
+    return SDMI_OK;
+  }
+
+  // conv_input, then layernorm_1 + in_proj (q | k | v, V transposed for the attention kernel) as one launch (b2b.hip)
+  int b2b_qkv(const Act& a1, const ConvW& w1, const Act& s_out, const FoldW& f2, float cscale, const Act& qk, f16* vt, int S, int ldt) {
+    B2bArgs t;
+    memset(&t, 0, sizeof(t));
+    t.a1 = a1.h; t.lda1 = a1.C; t.w1 = w1.w; t.b1 = w1.bias;
+    t.s32 = s_out.f; t.s16 = s_out.h;
+    t.w2 = f2.w; t.K2 = 320; t.h2 = f2.h; t.cscale = cscale;
+    t.out = qk.h; t.ldo = qk.C; t.npass2 = 3; t.vt = vt; t.S = S; t.ldt = ldt;
+    t.M = a1.M(); t.eps = 1e-5f;
+    const double flops = 2.0 * t.M * 320.0 * (320.0 + 960.0);
+    prof_begin(0, flops);
+    TRY(sdmi_launch_b2b(t, st));
+    prof_end();
+    launches += 1;
+    log_launch("b2b M=%d K2=960 partial=0 flops=%.0f", t.M, flops);
     return SDMI_OK;
   }
 
@@ -889,14 +907,22 @@ struct Engine {
     TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s0));
     RowStat rs;
-    { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
-    // self-attention
-    if (!rs.ptr) TRY(layernorm(s0, w.ln1, &u));
+    // C = 320 (the 64x64 level): conv_input + in_proj, out_proj 1 + q_proj, and out_proj 2 + feed-forward, each as ONE
+    // back-to-back launch
+    static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
+    static const bool b2b_qkv_on = !(getenv("SDMI_B2B_QKV") && atoi(getenv("SDMI_B2B_QKV")) == 0);
+    static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
+    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0;
     TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
     if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
     if (Spad != S) { SDMI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)B * C * Spad * 2, st)); launches += 1; }
-    {
+    if (use_b2b && b2b_qkv_on && S % 32 == 0) {
+      TRY(b2b_qkv(t0, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));
+    } else {
+      { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
+      // self-attention
+      if (!rs.ptr) TRY(layernorm(s0, w.ln1, &u));
       GemmArgs a = base_args(rs.ptr ? s0 : u, nullptr, w.in_proj, x.H, x.W, 1, 0);
       if (rs.ptr) fold_ln(a, w.in_proj_f, rs, C);
       a.out = qk.h; a.ldc = 2 * C;
@@ -907,10 +933,6 @@ struct Engine {
     TRY(new_act(B, x.H, x.W, C, false, &ao));
     TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s1));
-    // C = 320 (the 64x64 level): out_proj 1 + q_proj, and out_proj 2 + feed-forward, each as ONE back-to-back launch
-    static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
-    static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
-    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0;
     bool q_done = false;
     if (use_b2b) {
       TRY(new_act(B, x.H, x.W, C, false, &q2));

@@ -522,3 +522,46 @@ def test_back_to_back_gemm(M, partial, stream_f32, bm):
     if partial and stream_f32:
         assert torch.equal(out16.cpu(), out.cpu().half())
     G.log_metric(test="b2b", M=M, partial=partial, stream_f32=stream_f32, rel_l2=rel, max_abs=err)
+
+
+@pytest.mark.parametrize("Bn,S,bm", [(2, 64, 64), (2, 96, 32), (1, 256, 32), (3, 32, 32)])
+def test_back_to_back_gemm_qkv(Bn, S, bm):
+    """b2b three-pass form: conv_input (1x1) then layernorm_1 + in_proj in one launch (sd/diffusion.py:312-321,
+    sd/attention.py:42-52): q (pre-scaled) | k row-major, v transposed in the attention kernel's key order."""
+    import ctypes as C
+    Cc, M = 320, Bn * S
+    g = torch.Generator().manual_seed(S + Bn)
+    a1 = torch.randn((M, Cc), generator=g).half()
+    w1 = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    b1 = torch.randn((Cc,), generator=g)
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    w2 = torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)
+    s_ref = a1.double() @ w1.double().t() + b1.double()
+    qkv = F.layer_norm(s_ref, (Cc,), gamma.double(), beta.double(), 1e-5) @ w2.double().t()
+    wf, _, hf = G.ln_fold_prep(w2.to(DEV), gamma.to(DEV), beta.to(DEV), None)
+    Spad = (S + 63) // 64 * 64
+    a1d, w1d, b1d = a1.to(DEV), w1.to(DEV), b1.to(DEV)
+    s32 = torch.full((M, Cc), float("nan"), device=DEV)
+    s16 = torch.full((M, Cc), float("nan"), dtype=torch.float16, device=DEV)
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=torch.float16, device=DEV)
+    vt = torch.zeros((Bn * Cc, Spad), dtype=torch.float16, device=DEV)
+    d = N_.B2bDesc()
+    d.a1, d.lda1, d.w1, d.b1 = a1d.data_ptr(), Cc, w1d.data_ptr(), b1d.data_ptr()
+    d.s32, d.s16 = s32.data_ptr(), s16.data_ptr()
+    d.w2, d.K2, d.h2, d.partial, d.cscale = wf.data_ptr(), 320, hf.data_ptr(), 0, 0.5
+    d.out, d.out_f32, d.ldo, d.npass2 = qk.data_ptr(), 0, 2 * Cc, 3
+    d.vt, d.S, d.ldt = vt.data_ptr(), S, Spad
+    d.M, d.eps, d.bm = M, 1e-5, bm
+    N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b qkv")
+    torch.cuda.synchronize()
+    assert (s32.cpu().double() - s_ref).abs().max().item() < 4e-3
+    got = qk.float().cpu().double()
+    eq = (got[:, :Cc] - 0.5 * qkv[:, :Cc]).abs().max().item()
+    ek = (got[:, Cc:] - qkv[:, Cc:2 * Cc]).abs().max().item()
+    vnat = G.vt_natural_order(vt)[:, :S].float().cpu().double().view(Bn, Cc, S).permute(0, 2, 1).reshape(M, Cc)
+    ev = (vnat - qkv[:, 2 * Cc:]).abs().max().item()
+    assert eq < 1.5e-2 and ek < 2e-2 and ev < 2e-2, (eq, ek, ev)
+    if Spad != S:
+        assert G.vt_natural_order(vt)[:, S:].abs().max().item() == 0.0      # key padding untouched
+    G.log_metric(test="b2b_qkv", B=Bn, S=S, bm=bm, q_err=eq, k_err=ek, v_err=ev)

@@ -62,5 +62,35 @@ def main():
                   % tuple(x - t0 for x in dm[:8]))
 
 
+def qkv(M=8192, S=4096):
+    """conv_input + layernorm_1 + in_proj (three-pass form)"""
+    dev, Cc = "cuda", 320
+    lib = N.load()
+    g = torch.Generator().manual_seed(1)
+    a1 = torch.randn((M, Cc), generator=g).half().to(dev)
+    w1 = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half().to(dev)
+    b1 = torch.randn((Cc,), generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn((Cc,), generator=g)).to(dev)
+    beta = (0.1 * torch.randn((Cc,), generator=g)).to(dev)
+    w2 = (torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)).to(dev)
+    wf, _, hf = G.ln_fold_prep(w2, gamma, beta, None)
+    s32 = torch.empty((M, Cc), device=dev)
+    s16 = torch.empty((M, Cc), dtype=torch.float16, device=dev)
+    qk = torch.empty((M, 2 * Cc), dtype=torch.float16, device=dev)
+    vt = torch.zeros((M // S * Cc, S), dtype=torch.float16, device=dev)
+    for bm in (64, 32):
+        d = N.B2bDesc()
+        d.a1, d.lda1, d.w1, d.b1 = a1.data_ptr(), Cc, w1.data_ptr(), b1.data_ptr()
+        d.s32, d.s16 = s32.data_ptr(), s16.data_ptr()
+        d.w2, d.K2, d.h2, d.cscale = wf.data_ptr(), 320, hf.data_ptr(), 0.25
+        d.out, d.ldo, d.npass2, d.vt, d.S, d.ldt = qk.data_ptr(), 2 * Cc, 3, vt.data_ptr(), S, S
+        d.M, d.eps, d.bm = M, 1e-5, bm
+        us = C.c_float(0)
+        N.check(lib.sdmi_op_b2b(C.byref(d), 50, C.byref(us), N.cur_stream()), "b2b qkv")
+        torch.cuda.synchronize()
+        print(f"b2b qkv M={M} BM={bm}: {us.value:.2f} us / launch (warm, back to back)")
+
+
 if __name__ == "__main__":
     main()
+    qkv(int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 4096 if len(sys.argv) < 2 or int(sys.argv[1]) == 8192 else int(sys.argv[1]) // 2)
