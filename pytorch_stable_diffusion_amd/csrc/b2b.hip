@@ -418,20 +418,20 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) af[s][e] = (f16)fmaf((float)af[s][e], rsd, nmr);     // v_fma_mix: (s - mean) rstd
       }
-      // W fragments of column block j+1 are read before the MFMAs of block j (double-buffered in registers), so the LDS
-      // latency hides under the matrix pipe instead of being paid five times per K-step
-      f16x8 bf[2][4];
+      // The 20 W fragments of a K-step (5 column blocks x 4 k16 sub-steps) go through a 6-deep register ring, each read
+      // four MFMAs ahead of its use: the LDS latency hides under the matrix pipe, at 24 registers instead of the 32 of a
+      // whole double-buffered block (the kernel sits at the 168-register limit of three waves per SIMD).
+      f16x8 bf[6];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bf[0][s] = *(const f16x8*)(bp + (((2 * s + h) ^ key) << 4));
+      for (int q = 0; q < 4; ++q) bf[q] = *(const f16x8*)(bp + (q >> 2) * 32 * 128 + (((2 * (q & 3) + h) ^ key) << 4));
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        if (j < 4) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) bf[(j + 1) & 1][s] = *(const f16x8*)(bp + (j + 1) * 32 * 128 + (((2 * s + h) ^ key) << 4));
+      for (int q = 0; q < 20; ++q) {
+        if (q + 4 < 20) {
+          const int qq = q + 4;
+          bf[qq % 6] = *(const f16x8*)(bp + (qq >> 2) * 32 * 128 + (((2 * (qq & 3) + h) ^ key) << 4));
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], bf[j & 1][s], acc[j], 0, 0, 0);
+        acc[q >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 3], bf[q % 6], acc[q >> 2], 0, 0, 0);
       }
     };
     auto acc_to_lds = [&]() {
