@@ -321,7 +321,7 @@ int sdmi_gn_nchunk(int P) {
 
 // 1 when the single-launch kernel takes this shape (slab of one group fits the block's registers), else 2
 int sdmi_gn_launches(const GnArgs& a) {
-  static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 256;   // measured: 64 blocks cannot pull larger maps fast enough
+  static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 1024;   // up to 32x32 the one launch is as fast as stats + apply (same-box 4.277 vs 4.281 ms/step, 11 launches fewer); beyond, 64 blocks cannot pull the map fast enough
   const int C = a.C0 + a.C1, cpg = C / 32;
   const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
   return (cpg % 4 == 0 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
