@@ -202,6 +202,11 @@ typedef struct sdmi_b2b_desc {
    * in the key order sdmi_op_attention reads.  ldo = 0: 320. */
   int npass2, ldo;
   void* vt; int S, ldt;
+  /* gx != NULL: the first product's A operand is GroupNorm(gx) (32 groups, eps gn_eps, no SiLU: the attention block's
+   * groupnorm, sd/diffusion.py:294,312) computed in the kernel from the raw [M][320] tensor gx (fp32 if gx_f32) and the
+   * partial statistics sdmi_op_gn_stats wrote ([B][gn_nchunk][32][2]); images of S rows, S % 32 == 0; a1 is ignored. */
+  const void* gx; int gx_f32;
+  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
 } sdmi_b2b_desc;
 int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);

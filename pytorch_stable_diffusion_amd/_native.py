@@ -46,7 +46,9 @@ class B2bDesc(C.Structure):
                 ("w2", C.c_void_p), ("K2", C.c_int), ("h2", C.c_void_p), ("partial", C.c_int), ("cscale", C.c_float),
                 ("r2", C.c_void_p), ("r2_f32", C.c_int), ("out", C.c_void_p), ("out_f32", C.c_int), ("out16", C.c_void_p),
                 ("M", C.c_int), ("eps", C.c_float), ("bm", C.c_int),
-                ("npass2", C.c_int), ("ldo", C.c_int), ("vt", C.c_void_p), ("S", C.c_int), ("ldt", C.c_int)]
+                ("npass2", C.c_int), ("ldo", C.c_int), ("vt", C.c_void_p), ("S", C.c_int), ("ldt", C.c_int),
+                ("gx", C.c_void_p), ("gx_f32", C.c_int), ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int),
+                ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float)]
 
 
 _LIB: Optional[C.CDLL] = None

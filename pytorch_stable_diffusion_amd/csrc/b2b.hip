@@ -161,11 +161,80 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
 
     // ---- product 1, epilogue 1: S = A1 W1^T + b1 + R1, its fp16 copy into the A-operand panels, row statistics ----
     B2B_STAMP(1, 0);
-    issue(p.w1, kC, 0, true, 0);
-    issue(p.w1, kC, 64, true, 1);
+    const bool gn_in = p.gx != nullptr;                  // A1 = GroupNorm(gx) computed here (no A1 tensor, no A1 ring)
+    issue(p.w1, kC, 0, !gn_in, 0);
+    issue(p.w1, kC, 64, !gn_in, 1);
+    if (gn_in) {
+      // GroupNorm(32 groups of 10 channels) of this tile's rows, as gn_apply_kernel (norm.hip) does it: group statistics
+      // from the chunk partials of gn_stats_kernel summed in fp64 (lane g of every wave owns group g), then
+      // y = (x - mean) rstd gamma + beta in fp32, rounded to fp16 into the A-operand panels of the first product.
+      const int img = m0 / p.S;
+      // the rows first: their (cold) loads fly while the statistics are reduced
+      f32x4 xv[kNR][2];
+#pragma unroll
+      for (int i = 0; i < kNR; ++i) {
+        const size_t off = (size_t)(m0 + dw + 8 * i) * kC;
+        if (p.gx_f32) {
+          xv[i][0] = own ? *(const f32x4*)((const float*)p.gx + off + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+          xv[i][1] = own ? *(const f32x4*)((const float*)p.gx + off + c1) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          const f16x4 t0 = own ? *(const f16x4*)((const f16*)p.gx + off + c0) : f16x4{};
+          const f16x4 t1 = own ? *(const f16x4*)((const f16*)p.gx + off + c1) : f16x4{};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xv[i][0][e] = (float)t0[e]; xv[i][1][e] = (float)t1[e]; }
+        }
+      }
+      // lane (half, g): chunks j = half, half + 2, ... of group g, two interleaved fp64 chains (a single 128-long chain of
+      // dependent fp64 adds cost ~2 us at the start of every workgroup); the halves meet through one shuffle
+      double gs0 = 0.0, gq0 = 0.0, gs1 = 0.0, gq1 = 0.0;
+      const float* pp = p.gn_partial + ((size_t)img * p.gn_nchunk * 32 + (lane & 31)) * 2;
+#pragma unroll 4
+      for (int j = lane >> 5; j < p.gn_nchunk; j += 4) {
+        const f32x2 t = *(const f32x2*)(pp + (size_t)j * 64);
+        gs0 += (double)t[0]; gq0 += (double)t[1];
+        if (j + 2 < p.gn_nchunk) {
+          const f32x2 u = *(const f32x2*)(pp + (size_t)(j + 2) * 64);
+          gs1 += (double)u[0]; gq1 += (double)u[1];
+        }
+      }
+      double gs = gs0 + gs1, gq = gq0 + gq1;
+      gs += __shfl_xor(gs, 32);
+      gq += __shfl_xor(gq, 32);
+      const double cnt = (double)(kC / 32) * (double)p.S;
+      const double gmean = gs / cnt;
+      double gvar = gq / cnt - gmean * gmean;
+      gvar = gvar < 0.0 ? 0.0 : gvar;
+      const float mean_g = (float)gmean, rstd_g = rsqrtf((float)gvar + p.gn_eps);
+      float cm[2][4], cg[2][4], cb[2][4];                // per owned channel: group mean, rstd * gamma, beta
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = (own ? (q ? c1 : c0) : 0) + e;
+          const int g = c / (kC / 32);
+          cm[q][e] = __shfl(mean_g, g);
+          cg[q][e] = __shfl(rstd_g, g) * p.gn_gamma[c];
+          cb[q][e] = p.gn_beta[c];
+        }
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) {
+          const int row = dw + 8 * i;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            f16x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (f16)((xv[i][q][e] - cm[q][e]) * cg[q][e] + cb[q][e]);
+            const int n = q ? c1 : c0;
+            *(f16x4*)(S16 + (n >> 6) * kAStage + row * 128 + (((((n >> 3) & 7) ^ ((row >> 1) & 7))) << 4) + (n & 7) * 2) = a;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // panels written before the first barrier of the product
+    }
     fetch(p.r1, p.r1_f32, p.b1);                         // >= two loads per row when there is a residual
     B2B_STAMP(1, 1);
-    stream(p.w1, kC, kC / 64, true, p.r1 ? 2 * kNR : 0);
+    stream(p.w1, kC, kC / 64, !gn_in, (!gn_in && p.r1) ? 2 * kNR : 0);
     B2B_STAMP(1, 2);
     __syncthreads();                                     // B1: every ring read retired
     __syncthreads();                                     // B2: accumulators are in Cs
@@ -450,7 +519,7 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
       __builtin_amdgcn_s_barrier();
       if (t == 0) B2B_STAMP(0, 1);
       const int st = t % kNS;
-      compute(S16 + st * kAStage, ring + st * kWStage, false);
+      compute(p.gx ? S16 + t * kAStage : S16 + st * kAStage, ring + st * kWStage, false);   // panels (GroupNorm input) or A1 ring
     }
     B2B_STAMP(0, 2);
     __syncthreads();                                     // B1
@@ -507,13 +576,16 @@ int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm) {
   SDMI_REQUIRE(a.M > 0 && a.M % 32 == 0, "b2b: M=%d must be a positive multiple of 32", a.M);
   SDMI_REQUIRE(a.K2 == kC || (a.K2 == 2 * kC && a.partial), "b2b: K2=%d (C = %d: K2 = C, or 2C with the partial fold)", a.K2, kC);
   SDMI_REQUIRE(!a.partial || a.K2 == 2 * kC, "b2b: the partial fold needs K2 = 2C");
-  SDMI_REQUIRE(a.a1 && a.w1 && a.b1 && a.w2 && a.h2 && a.out && a.lda1 >= kC && a.lda1 % 8 == 0, "b2b: null pointer / bad lda");
+  SDMI_REQUIRE((a.a1 || a.gx) && a.w1 && a.b1 && a.w2 && a.h2 && a.out && (a.gx || (a.lda1 >= kC && a.lda1 % 8 == 0)), "b2b: null pointer / bad lda");
+  SDMI_REQUIRE(!a.gx || (a.gn_partial && a.gn_gamma && a.gn_beta && a.gn_nchunk > 0 && a.S > 0 && a.S % 32 == 0 && a.M % a.S == 0),
+               "b2b: the GroupNorm input form needs the statistics partials, gamma / beta and whole 32-row tiles per image");
   SDMI_REQUIRE(a.npass2 == 1 || (a.npass2 == 3 && !a.partial && !a.r2 && !a.out_f32 && a.vt && a.S > 0 && a.S % 32 == 0 && a.M % a.S == 0 &&
                                  a.ldt >= a.S && a.ldt % 8 == 0),
                "b2b: the three-pass form (q | k | v) needs fp16 outputs, no residual, a V^T target and S %% 32 == 0");
   SDMI_REQUIRE(a.ldo >= a.npass2 * kC - (a.npass2 == 3 ? kC : 0) && a.ldo % 8 == 0, "b2b: output row stride %d", a.ldo);
   if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256 || (a.npass2 == 3 && a.S % 64 != 0)) ? 32 : 64;
-  SDMI_REQUIRE(a.npass2 == 1 || a.S % bm == 0, "b2b: a %d-row tile would straddle images of %d tokens", bm, a.S);
+  if (a.gx && a.S % 64 != 0) bm = 32;
+  SDMI_REQUIRE((a.npass2 == 1 && !a.gx) || a.S % bm == 0, "b2b: a %d-row tile would straddle images of %d tokens", bm, a.S);
   SDMI_REQUIRE((bm == 32 || bm == 64) && a.M % bm == 0, "b2b: tile height %d does not divide M=%d", bm, a.M);
   return bm == 32 ? launch_b2b<32>(a, st) : launch_b2b<64>(a, st);
 }

@@ -139,6 +139,11 @@ struct B2bArgs {
   // attention kernel's key order (gemm.hip vt_pos), m = b*S + s.  npass2 = 1: one pass, out[M][ldo].
   int npass2, ldo;
   f16* vt; int S, ldt;
+  // gx != nullptr: the first product's A operand is GroupNorm(gx) (32 groups, no SiLU: sd/diffusion.py:294,312), computed
+  // in the kernel from the raw stream gx [M][320] (fp32 or fp16) and gn_stats_kernel's partials ([B][gn_nchunk][32][2],
+  // images of S rows); a1 is unused.
+  const void* gx; int gx_f32;
+  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
 };
 int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M
 int sdmi_gemm_num_cfgs();

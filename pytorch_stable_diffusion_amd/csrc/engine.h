@@ -846,10 +846,16 @@ struct Engine {
   }
 
   // conv_input, then layernorm_1 + in_proj (q | k | v, V transposed for the attention kernel) as one launch (b2b.hip)
-  int b2b_qkv(const Act& a1, const ConvW& w1, const Act& s_out, const FoldW& f2, float cscale, const Act& qk, f16* vt, int S, int ldt) {
+  // gn != null: a1 is the RAW stream and the block's GroupNorm (statistics already in gn_partial) is applied inside the kernel
+  int b2b_qkv(const Act& a1, const NormW* gn, const ConvW& w1, const Act& s_out, const FoldW& f2, float cscale, const Act& qk,
+              f16* vt, int S, int ldt) {
     B2bArgs t;
     memset(&t, 0, sizeof(t));
     t.a1 = a1.h; t.lda1 = a1.C; t.w1 = w1.w; t.b1 = w1.bias;
+    if (gn) {
+      t.gx = a1.f ? (const void*)a1.f : (const void*)a1.h; t.gx_f32 = a1.f != nullptr;
+      t.gn_partial = gn_partial; t.gn_nchunk = sdmi_gn_nchunk(S); t.gn_gamma = gn->gamma; t.gn_beta = gn->beta; t.gn_eps = 1e-6f;
+    }
     t.s32 = s_out.f; t.s16 = s_out.h;
     t.w2 = f2.w; t.K2 = 320; t.h2 = f2.h; t.cscale = cscale;
     t.out = qk.h; t.ldo = qk.C; t.npass2 = 3; t.vt = vt; t.S = S; t.ldt = ldt;
@@ -904,7 +910,6 @@ struct Engine {
     // 202.3 steps/s, attention blocks rel-L2 1.9e-4 vs 1.6e-4, 50-step txt2img pixel MAE 6.97e-4 vs 6.30e-4.  The default
     // keeps the fp32 copies: 1.6 % of speed is not worth 10 % of the parity budget.
     static const bool inner_f32 = getenv("SDMI_ATTN_INNER_F16") == nullptr;
-    TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s0));
     RowStat rs;
     // C = 320 (the 64x64 level): conv_input + in_proj, out_proj 1 + q_proj, and out_proj 2 + feed-forward, each as ONE
@@ -917,9 +922,19 @@ struct Engine {
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
     if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
     if (Spad != S) { SDMI_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)B * C * Spad * 2, st)); launches += 1; }
-    if (use_b2b && b2b_qkv_on && S % 32 == 0) {
-      TRY(b2b_qkv(t0, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));
+    // SDMI_B2B_GN=1: the block's GroupNorm is applied inside the back-to-back kernel as well (statistics launch only).
+    // Parity-green and measured time-neutral on one MI355X (same box: 4.173 vs 4.171 ms/step, 5 launches and 0.05 GB of
+    // traffic fewer): the kernel's start-up takes what the 8.8 us gn_apply gave back, so the default keeps gn_apply.
+    static const bool b2b_gn_on = getenv("SDMI_B2B_GN") && atoi(getenv("SDMI_B2B_GN")) != 0;
+    if (use_b2b && b2b_qkv_on && S % 32 == 0 && b2b_gn_on) {
+      // groupnorm + conv_input + layernorm_1 + in_proj: statistics launch, then everything else in the back-to-back kernel
+      TRY(gn_stats(x, nullptr));
+      TRY(b2b_qkv(x, &w.gn, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));
+    } else if (use_b2b && b2b_qkv_on && S % 32 == 0) {
+      TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
+      TRY(b2b_qkv(t0, nullptr, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));
     } else {
+      TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
       { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
       // self-attention
       if (!rs.ptr) TRY(layernorm(s0, w.ln1, &u));

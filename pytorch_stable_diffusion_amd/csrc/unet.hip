@@ -497,6 +497,8 @@ int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* str
   a.cscale = d->cscale; a.r2 = d->r2; a.r2_f32 = d->r2_f32; a.out = d->out; a.out_f32 = d->out_f32; a.out16 = (f16*)d->out16;
   a.M = d->M; a.eps = d->eps;
   a.npass2 = d->npass2 > 0 ? d->npass2 : 1; a.ldo = d->ldo > 0 ? d->ldo : 320; a.vt = (f16*)d->vt; a.S = d->S; a.ldt = d->ldt;
+  a.gx = d->gx; a.gx_f32 = d->gx_f32; a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma;
+  a.gn_beta = d->gn_beta; a.gn_eps = d->gn_eps;
   hipStream_t st = (hipStream_t)stream;
   if (!us_per_iter) {
     for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st, d->bm));

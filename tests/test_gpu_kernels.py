@@ -524,8 +524,9 @@ def test_back_to_back_gemm(M, partial, stream_f32, bm):
     G.log_metric(test="b2b", M=M, partial=partial, stream_f32=stream_f32, rel_l2=rel, max_abs=err)
 
 
-@pytest.mark.parametrize("Bn,S,bm", [(2, 64, 64), (2, 96, 32), (1, 256, 32), (3, 32, 32)])
-def test_back_to_back_gemm_qkv(Bn, S, bm):
+@pytest.mark.parametrize("Bn,S,bm,gn", [(2, 64, 64, 0), (2, 96, 32, 0), (1, 256, 32, 0), (3, 32, 32, 0),
+                                        (2, 64, 64, 1), (2, 1024, 32, 1), (1, 96, 32, 2), (2, 256, 64, 2)])
+def test_back_to_back_gemm_qkv(Bn, S, bm, gn):
     """b2b three-pass form: conv_input (1x1) then layernorm_1 + in_proj in one launch (sd/diffusion.py:312-321,
     sd/attention.py:42-52): q (pre-scaled) | k row-major, v transposed in the attention kernel's key order."""
     import ctypes as C
@@ -537,6 +538,17 @@ def test_back_to_back_gemm_qkv(Bn, S, bm):
     gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
     beta = 0.1 * torch.randn((Cc,), generator=g)
     w2 = torch.randn((3 * Cc, Cc), generator=g) / math.sqrt(Cc)
+    gx = None
+    if gn:
+        # gn = 1 / 2: the first product's A operand is GroupNorm(32) of a raw fp32 / fp16 tensor with per-channel offsets
+        # (sd/diffusion.py:294,312), normalised inside the kernel from sdmi_op_gn_stats' partials
+        gx = torch.randn((M, Cc), generator=g) * (0.5 + torch.rand((Cc,), generator=g)) + 3.0 * torch.randn((Cc,), generator=g)
+        if gn == 2:
+            gx = gx.half().float()
+        ggam = 1 + 0.2 * torch.randn((Cc,), generator=g)
+        gbet = 0.2 * torch.randn((Cc,), generator=g)
+        xn = F.group_norm(gx.double().view(Bn, S, Cc).permute(0, 2, 1), 32, ggam.double(), gbet.double(), 1e-6)
+        a1 = xn.permute(0, 2, 1).reshape(M, Cc).half()       # the kernel rounds the normalised operand to fp16 as well
     s_ref = a1.double() @ w1.double().t() + b1.double()
     qkv = F.layer_norm(s_ref, (Cc,), gamma.double(), beta.double(), 1e-5) @ w2.double().t()
     wf, _, hf = G.ln_fold_prep(w2.to(DEV), gamma.to(DEV), beta.to(DEV), None)
@@ -553,15 +565,26 @@ def test_back_to_back_gemm_qkv(Bn, S, bm):
     d.out, d.out_f32, d.ldo, d.npass2 = qk.data_ptr(), 0, 2 * Cc, 3
     d.vt, d.S, d.ldt = vt.data_ptr(), S, Spad
     d.M, d.eps, d.bm = M, 1e-5, bm
+    if gn:
+        lib = N_.load()
+        gxd = gx.to(DEV) if gn == 1 else gx.half().to(DEV)
+        nch = lib.sdmi_gn_num_chunks(S)
+        part = torch.zeros((Bn, nch, 32, 2), device=DEV)
+        N_.check(lib.sdmi_op_gn_stats(N_.ptr(gxd), None, int(gn == 1), Cc, 0, Bn, S, N_.ptr(part), N_.cur_stream()), "gn_stats")
+        gg, gb = ggam.to(DEV), gbet.to(DEV)
+        d.a1 = 0
+        d.gx, d.gx_f32, d.gn_partial, d.gn_nchunk = gxd.data_ptr(), int(gn == 1), part.data_ptr(), nch
+        d.gn_gamma, d.gn_beta, d.gn_eps = gg.data_ptr(), gb.data_ptr(), 1e-6
     N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b qkv")
     torch.cuda.synchronize()
-    assert (s32.cpu().double() - s_ref).abs().max().item() < 4e-3
+    assert (s32.cpu().double() - s_ref).abs().max().item() < (4e-3 if not gn else 2.5e-2)    # gn: an fp16 ulp of the A operand flips
     got = qk.float().cpu().double()
     eq = (got[:, :Cc] - 0.5 * qkv[:, :Cc]).abs().max().item()
     ek = (got[:, Cc:] - qkv[:, Cc:2 * Cc]).abs().max().item()
     vnat = G.vt_natural_order(vt)[:, :S].float().cpu().double().view(Bn, Cc, S).permute(0, 2, 1).reshape(M, Cc)
     ev = (vnat - qkv[:, 2 * Cc:]).abs().max().item()
-    assert eq < 1.5e-2 and ek < 2e-2 and ev < 2e-2, (eq, ek, ev)
+    lim = 1.0 if not gn else 2.0
+    assert eq < 1.5e-2 * lim and ek < 2e-2 * lim and ev < 2e-2 * lim, (eq, ek, ev)
     if Spad != S:
         assert G.vt_natural_order(vt)[:, S:].abs().max().item() == 0.0      # key padding untouched
     G.log_metric(test="b2b_qkv", B=Bn, S=S, bm=bm, q_err=eq, k_err=ek, v_err=ev)
