@@ -1,25 +1,29 @@
-// Back-to-back GEMM for the 320-channel attention blocks (sd/diffusion.py:321-363 at the 64x64 level):
+// Back-to-back GEMM for the 320-channel attention blocks (sd/diffusion.py:312-363 at the 64x64 level):
 //
-//     S = A1 W1^T + b1 + R1                      (attention out_proj + residual: sd/diffusion.py:325,343)
+//     S = A1 W1^T + b1 (+ R1)                    (conv_input, or an attention out_proj + residual: sd/diffusion.py:312,325,343)
 //     Y = f(LayerNorm(S)) W2^T ... + b2 (+ R2)   (the next Linear, with the LayerNorm folded as in gemm.hip)
 //
-// in ONE launch: a workgroup owns 64 full rows (all 320 columns), so the row statistics of S are available in-tile and the
-// fp16 copy of S stays in LDS as the A operand of the second product.  Two forms of the second product:
+// in ONE launch: a workgroup owns 32 or 64 full rows (all 320 columns), so the row statistics of S are available in-tile and
+// the fp16 copy of S stays in LDS as the A operand of the second product.  Forms of the second product:
 //   full fold   (partial = 0):  Y = cscale * (LN0(S) W2'^T + h)                       -- q_proj after out_proj 1
 //   partial fold(partial = 1):  Y = LN0(S) W2a'^T + S W2b^T + h + R2,  W2 = [W2a' | W2b] -- the composed feed-forward
-// with LN0(S) = (S - mean) rstd, W2' = gamma (.) W2 and h = b + W2 beta (sdmi_launch_ln_fold_prep).
+//   three passes (npass2 = 3):  [q | k | v] = LN0(S) W2'^T + h, 320 columns per pass    -- in_proj after conv_input; q scaled,
+//                               v written transposed in the attention kernel's key order
+// with LN0(S) = (S - mean) rstd, W2' = gamma (.) W2 and h = b + W2 beta (sdmi_launch_ln_fold_prep).  Optionally (gx) the
+// first A operand is the block's GroupNorm of the raw stream, applied by the DMA waves on the way into LDS.
 // The K = C GEMMs of these blocks are bound by launch latency plus the fp32 stream's bytes (gemm.hip: ~5 us + bytes / 5 TB/s
 // for 1.7 GFLOP); fusing a pair removes one launch, the re-read of S and -- for the feed-forward, whose input nobody
 // else reads -- the 15.7 MB write of S.
 //
-// Workgroup = 12 waves: 4 MFMA waves (32 rows x 160 columns each: 5 accumulator blocks of 32x32) and 8 DMA waves that
-// stream the 320x64 weight tile (+ the 64x64 A1 tile) of each K-step into a THREE-stage LDS ring with global_load_lds
-// (counted vmcnt: two tiles in flight while one is multiplied -- with two stages every K-step waited a full L2 latency);
-// one s_barrier per K-step.  LDS, all 160 KiB: weight ring 3 x 40 KiB (aliased by the fp32 tile of both epilogues) + 40 KiB
-// that hold the A1 ring during the first product and then S as fp16 in the A-operand layout (five 64-column panels,
-// 16-byte chunks XOR-swizzled on the row).  The LayerNorm is applied to the A fragments in registers on their way from LDS
-// to the MFMA (each lane reads one row: two statistics registers), gamma / beta are in the folded weights and bias; both
-// epilogues are plain bias + residual passes over rows whose residuals were fetched into registers before the product.
+// Workgroup = 2 or 4 MFMA waves (32 rows x 160 columns each: 5 accumulator blocks of 32x32) + 8 DMA waves that stream the
+// 320x64 weight tile (+ the A1 tile) of each K-step into a THREE-stage LDS ring with global_load_lds (counted vmcnt: two
+// tiles in flight while one is multiplied -- with two stages every K-step waited a full L2 latency); one s_barrier per
+// K-step.  LDS: weight ring 3 x 40 KiB (aliased by the fp32 tile of the epilogues) + 20 / 40 KiB that hold the A1 ring during
+// the first product and then S as fp16 in the A-operand layout (five 64-column panels, 16-byte chunks XOR-swizzled on the
+// row).  The LayerNorm is applied when the panels are written (full fold) or to the A fragments in registers on their way to
+// the MFMA (partial fold: the plain half needs S itself); gamma / beta are in the folded weights and bias.  The DMA waves
+// run both epilogues (the MFMA waves keep their registers for accumulators) over rows whose residuals were fetched into
+// registers before the product -- a load-use chain per row cost six cold latencies per epilogue.
 #include "common.h"
 
 namespace {
