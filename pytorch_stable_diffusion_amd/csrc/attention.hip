@@ -14,7 +14,12 @@
 //     carries 88% of attention FLOPs); V^T tile rows are 128 B with the GEMM's XOR swizzle.
 //   * the head-dim contraction is zero-padded on the Q fragment only (d=40 -> 48).
 //   * keys >= Skv are masked (cross-attention: 77 keys in a 128-key double tile).
+//   * SPLIT (short sequences, Sq <= 1024): a workgroup takes 64 queries and its wave pairs split the KEYS in two halves,
+//     each wave running the online softmax over its half; the pair merges (max, sum, O) through LDS at the end.  The
+//     tile loop is a dependent chain (~1 us per 64-key tile), so at S = 1024 / 256 the kernel was latency-bound with
+//     128 / 32 workgroups on 256 CUs: halving the chain and doubling the workgroups is worth more than the merge costs.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -41,32 +46,37 @@ struct ACfg {
   static constexpr int LDS = 2 * STAGE;
 };
 
-template <int D>
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   typedef ACfg<D> C;
+  constexpr int NSUB = SPLIT ? 2 : 1;                 // key streams staged per step (SPLIT: one tile of each half)
+  constexpr int STAGE2 = NSUB * C::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / p.H, head = bh % p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  const int ntiles = (p.Skv + 63) >> 6;
+  const int hk = SPLIT ? (wave & 1) : 0;              // which half of the keys this wave reduces
+  const int q0 = SPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+  const int ntiles = SPLIT ? (p.Skv >> 7) : (p.Skv + 63) >> 6;   // tiles per stream (SPLIT: Skv % 128 == 0, launcher)
 
   const f16* kbase = p.k + (size_t)b * p.k_batch_stride * p.ldk + head * D;
   const f16* vbase = p.vt + ((size_t)(b * p.H + head) * D) * p.ldvt;
 
   // per-lane LDS-DMA source pointers, advanced by one 64-key tile per stage() call
   constexpr int KI = (C::K_INST + 3) / 4, VI = C::V_INST / 4;
-  const f16* kptr[KI];
+  const f16* kptr[NSUB][KI];
   int krow[KI];
-  const f16* vptr[VI];
+  const f16* vptr[NSUB][VI];
   int vinc[VI];
+  const int half_keys = ntiles * 64;                   // SPLIT: first key of the second stream
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
     const int q = (i * 4 + wave) * 64 + lane;
     const int row = q / C::KCH, c = q - row * C::KCH;
     krow[i] = row;
-    kptr[i] = kbase + (size_t)row * p.ldk + c * 8;
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) kptr[u][i] = kbase + (size_t)(u * half_keys + row) * p.ldk + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < VI; ++i) {
@@ -75,28 +85,33 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const int gch = pc ^ ((row >> 1) & 7);
     // row D of the padded V^T tile is all ones: the PV MFMA then also produces the row sums of P (the softmax
     // denominator) in accumulator row D, and the VALU never adds the probabilities up
-    vptr[i] = row < D ? vbase + (size_t)row * p.ldvt + gch * 8 : ((C::LROW && row == D) ? p.ones : p.zero) + gch * 8;
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u)
+      vptr[u][i] = row < D ? vbase + (size_t)row * p.ldvt + u * half_keys + gch * 8 : ((C::LROW && row == D) ? p.ones : p.zero) + gch * 8;
     vinc[i] = row < D ? 64 : 0;
   }
   const size_t kstep = (size_t)64 * p.ldk;
   int stage_key0 = 0;
 
   auto stage = [&](int buf) {
-    char* sk = smem + buf * C::STAGE;
-    char* sv = sk + C::K_BYTES;
 #pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int ii = i * 4 + wave;
-      if (ii < C::K_INST) {
-        const f16* g = stage_key0 + krow[i] < p.Skv ? kptr[i] : p.zero;
-        glds16(g, sk + ii * 1024);
-        kptr[i] += kstep;
+    for (int u = 0; u < NSUB; ++u) {
+      char* sk = smem + buf * STAGE2 + u * C::STAGE;
+      char* sv = sk + C::K_BYTES;
+#pragma unroll
+      for (int i = 0; i < KI; ++i) {
+        const int ii = i * 4 + wave;
+        if (ii < C::K_INST) {
+          const f16* g = (SPLIT || stage_key0 + krow[i] < p.Skv) ? kptr[u][i] : p.zero;
+          glds16(g, sk + ii * 1024);
+          kptr[u][i] += kstep;
+        }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < VI; ++i) {
-      glds16(vptr[i], sv + (i * 4 + wave) * 1024);
-      vptr[i] += vinc[i];
+      for (int i = 0; i < VI; ++i) {
+        glds16(vptr[u][i], sv + (i * 4 + wave) * 1024);
+        vptr[u][i] += vinc[i];
+      }
     }
     stage_key0 += 64;
   };
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   auto tile_body = [&](auto masked_tag, auto first_tag, int t, int cur) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
-    const char* Ks = smem + cur * C::STAGE;
+    const char* Ks = smem + cur * STAGE2 + hk * C::STAGE;
     const char* Vs = Ks + C::K_BYTES;
     f32x16 sacc[2];
 #pragma unroll
@@ -238,8 +253,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   stage(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const bool ragged = (p.Skv & 63) != 0;
-  const int nfull = p.causal ? 0 : (ragged ? ntiles - 1 : ntiles);   // tiles that need no masking
+  const bool ragged = !SPLIT && (p.Skv & 63) != 0;
+  const int nfull = (!SPLIT && p.causal) ? 0 : (ragged ? ntiles - 1 : ntiles);   // tiles that need no masking
   // Three runs of tiles, each with ONE body in its loop (separate loops keep the accumulators in place: with both
   // bodies in one loop the register allocator copied all of O^T every tile): tile 0, unmasked tiles, masked tail.
   int cur = 0;
@@ -258,6 +273,32 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   for (; t < nfull; ++t) step(t, std::false_type{}, std::false_type{});
   for (; t < ntiles; ++t) step(t, std::true_type{}, std::false_type{});
 
+  if constexpr (SPLIT) {
+    // merge the pair's halves: wave hk = 1 hands (m, l, O^T) over through LDS (aliasing the K/V stages: every tile has been
+    // consumed), wave hk = 0 combines: m = max, O = O_a 2^(m_a - m) + O_b 2^(m_b - m) (the row of ones in V^T carries l
+    // along inside O for d = 40 / 80; d = 160 merges l_run explicitly), then normalises and stores as usual.
+    constexpr int NV = C::DB * 16 + 2;
+    __syncthreads();
+    float* mx = (float*)smem + ((size_t)(wave >> 1) * 64 + lane) * NV;
+    if (hk == 1) {
+#pragma unroll
+      for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx[d * 16 + e] = oacc[d][e];
+      mx[C::DB * 16] = m_run;
+      mx[C::DB * 16 + 1] = l_run;
+    }
+    __syncthreads();
+    if (hk == 1) return;
+    const float m_b = mx[C::DB * 16], l_b = mx[C::DB * 16 + 1];
+    const float m = fmaxf(m_run, m_b);
+    const float sa = __builtin_amdgcn_exp2f(m_run - m), sb = __builtin_amdgcn_exp2f(m_b - m);
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] = oacc[d][e] * sa + mx[d * 16 + e] * sb;
+    l_run = l_run * sa + l_b * sb;
+  }
   // ---- normalise and store: lane = query row, registers = head-dim ----
   float l_tot;
   if constexpr (C::LROW) l_tot = __shfl(oacc[D / 32][4 * ((D % 32) / 8)], r);   // accumulator row D (lane r of the low half)
@@ -286,11 +327,19 @@ int launch(const AttnArgs& a, hipStream_t st) {
   typedef ACfg<D> C;
   static bool attr_done = false;
   if (!attr_done) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS));
     attr_done = true;
   }
-  dim3 grid((a.Sq + 127) / 128, a.B * a.H);
-  hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), C::LDS, st, a);
+  // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
+  static const bool split_on = !(getenv("SDMI_ATTN_SPLIT") && atoi(getenv("SDMI_ATTN_SPLIT")) == 0);
+  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= 1024 && 2 * C::LDS <= 160 * 1024) {
+    dim3 grid(a.Sq / 64, a.B * a.H);
+    hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS, st, a);
+  } else {
+    dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+    hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), C::LDS, st, a);
+  }
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
