@@ -175,6 +175,10 @@ typedef struct sdmi_gemm_desc {
    * output parity: ks = 2, hs x ws = ho x wo = source size, M = 4*B*hs*ws (rows ordered phase, b, y, x), K = 4*(c0+c1),
    * w = sdmi_op_pack_ups_phase's [4][N][2][2][C], img_rows = M/4, w_img_stride = N*K; out is the (B, 2hs, 2ws, N) map. */
   int phase2;
+  /* ln_ksteps > 0: only the first ln_ksteps K-steps (of 64) are the LayerNorm-folded range, a plain product follows in the
+   * same accumulator (the composed feed-forward).  With ksplit > 1 the K-slices must end on that boundary and
+   * ln_out ([M][2] fp32 scratch) must be given. */
+  int ln_ksteps; float* ln_out;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */

@@ -37,7 +37,8 @@ class GemmDesc(C.Structure):
                 ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
                 ("gn_eps", C.c_float), ("gn_silu", C.c_int),
                 ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
-                ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int)]
+                ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int),
+                ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p)]
 
 
 class B2bDesc(C.Structure):

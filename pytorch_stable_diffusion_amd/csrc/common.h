@@ -110,6 +110,10 @@ struct GemmArgs {
   //    on top (the composed feed-forward of the attention block: y = LN(s) Wf^T + s Wo^T + b + x in one GEMM); the
   //    epilogue is then the plain bias (+ residual) one.  0: the whole K range is folded (epilogue form above).
   int ln_ksteps;
+  // split-K together with the partial fold (ksplit > 1, ln_ksteps > 0): K-slices end on the fold boundary, the slabs hold raw
+  // partial sums, workgroups (kz = 0, tn = 0) also write {mean, rstd} of their rows to ln_out[M][2], and splitk_finalize
+  // applies  rstd (sum of folded slabs - mean g) + sum of plain slabs + bias (+ res)
+  float* ln_out;
   // GroupNorm(32) (+SiLU) of the A operand fused into the 3x3 conv (conv3_gn_kernel; sd/diffusion.py:173-179,199-205):
   // a0 | a1 are the RAW activations; gn_partial = gn_stats_kernel's per-chunk {sum, sum of squares} per group
   // ([B][gn_nchunk][32][2]), reduced in the conv's prologue; y = silu(x * (rstd gamma) + (beta - mean rstd gamma)) is

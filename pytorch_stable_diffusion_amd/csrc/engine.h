@@ -594,7 +594,9 @@ struct Engine {
       for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
         if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
         if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
-        if (ks > 1 && (a0.ln_stat || (a0.img_rows && !a0.phase2) || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
+        if (ks > 1 && a0.ln_stat &&
+            !(a0.ln_ksteps > 0 && a0.ln_out && nkt % ks == 0 && a0.ln_ksteps % (nkt / ks) == 0 && cfg < sdmi_gemm_num_plain_cfgs())) continue;
+        if (ks > 1 && ((a0.img_rows && !a0.phase2) || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
@@ -1005,7 +1007,12 @@ struct Engine {
     TRY(new_act(B, x.H, x.W, C, true, y));
     {
       GemmArgs a = base_args(rs.ptr ? s2 : u, &s2, w.ffn, x.H, x.W, 1, 0);
-      if (rs.ptr) { fold_ln(a, w.ffn_f, rs, C); a.ln_ksteps = C / 64; }
+      if (rs.ptr) {
+        fold_ln(a, w.ffn_f, rs, C);
+        a.ln_ksteps = C / 64;
+        a.ln_out = (float*)arena.alloc((size_t)a.M * 8);        // lets the plan split K at the fold boundary (small maps)
+        if (!a.ln_out) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
+      }
       set_res(a, x);
       set_out(a, *y);
       TRY(gemm(a));

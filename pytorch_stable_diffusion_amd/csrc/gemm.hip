@@ -346,6 +346,10 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     var = var < 0.f ? 0.f : var;
     s_ln[2 * tid] = mean;
     s_ln[2 * tid + 1] = rsqrtf(var + p.ln_eps);
+    if (p.ln_out != nullptr && kz == 0 && tn == 0 && m0 + tid < p.M) {      // for splitk_finalize (partial fold + split-K)
+      p.ln_out[2 * (m0 + tid)] = mean;
+      p.ln_out[2 * (m0 + tid) + 1] = s_ln[2 * tid + 1];
+    }
   }
 
   const int Cin = p.C0 + p.C1;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
         }
       }
   };
-  const int ln_at = p.ln_stat != nullptr ? p.ln_ksteps : 0;     // K-step count after which to rescale (ksplit == 1: kt0 == 0)
+  const int ln_at = (p.ln_stat != nullptr && p.ksplit == 1) ? p.ln_ksteps : 0;   // K-step count after which to rescale (one-pass path; split-K rescales in splitk_finalize)
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_setup = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
@@ -1410,9 +1414,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     const unsigned mq = idx / n8;
     const int ms = (int)mq, n = (int)(idx - mq * n8) * 8;       // ms: slab row
     const int m = out_row(p, ms);                               // output row (phase2 scatter; identity otherwise)
-    float v[8];
+    float v[8], va[8];                 // va: slabs of the LayerNorm-folded K range (partial fold + split-K), v: the rest
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int e = 0; e < 8; ++e) { v[e] = 0.f; va[e] = 0.f; }
+    const int n_fold = (p.ln_stat != nullptr && p.ln_ksteps > 0) ? p.ln_ksteps / p.ksteps_per : 0;
     const bool transposed = p.outT != nullptr && n >= p.nt0;
     // residual issued first: it is the coldest load of the item
     f32x4 rf0 = {0.f, 0.f, 0.f, 0.f}, rf1 = {0.f, 0.f, 0.f, 0.f};
@@ -1441,10 +1446,20 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (z0 + j < p.ksplit) {
+          if (z0 + j < n_fold) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += s0[j][e]; v[4 + e] += s1[j][e]; }
+            for (int e = 0; e < 4; ++e) { va[e] += s0[j][e]; va[4 + e] += s1[j][e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += s0[j][e]; v[4 + e] += s1[j][e]; }
+          }
         }
       }
+    }
+    if (n_fold > 0) {
+      const float mean = p.ln_out[2 * ms], rstd = p.ln_out[2 * ms + 1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rstd * (va[e] - mean * p.ln_g[n + e]);
     }
     if (p.bias) {
 #pragma unroll
@@ -1656,7 +1671,10 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.K == a.ks * a.ks * (a.C0 + a.C1) + a.X0 + a.X1, "gemm: K=%d != ks^2*(C0+C1) + X0+X1", a.K);
   SDMI_REQUIRE(a.cs_hi % 8 == 0 && (a.cs_hi == 0 || !a.outT || a.cs_hi <= a.nt0), "gemm: scaled column range must be a multiple of 8 outside the transposed tail");
   SDMI_REQUIRE(!a.rowstat || (a.ksplit <= 1 && !a.outT), "gemm: row statistics need ksplit == 1 and no transposed tail");
-  SDMI_REQUIRE(!a.ln_stat || (a.ksplit <= 1 && a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && (!a.res || a.ln_ksteps > 0)), "gemm: bad LayerNorm-fold arguments");
+  SDMI_REQUIRE(!a.ln_stat || (a.ln_g && a.ln_ntn > 0 && a.ln_C > 0 && (!a.res || a.ln_ksteps > 0)), "gemm: bad LayerNorm-fold arguments");
+  SDMI_REQUIRE(!a.ln_stat || a.ksplit <= 1 ||
+                   (a.ln_ksteps > 0 && a.ln_out && (a.K / 64) % a.ksplit == 0 && a.ln_ksteps % ((a.K / 64) / a.ksplit) == 0 && a.ks == 1 && !a.img_rows),
+               "gemm: split-K with the LayerNorm fold needs the partial fold, ln_out, and K-slices that end on the fold boundary");
   SDMI_REQUIRE(a.ln_ksteps >= 0 && (a.ln_ksteps == 0 || (a.ln_stat && a.ks == 1 && !a.outT && a.ln_ksteps * 64 < a.K && a.ln_ksteps * 64 == a.ln_C)),
                "gemm: partial LayerNorm fold needs ln_stat, a 1x1 GEMM and ln_ksteps*64 == ln_C < K");
   SDMI_REQUIRE(a.X0 % 64 == 0 && a.X1 % 64 == 0 && (a.X0 == 0 || (a.x0 && a.ups == 0 && a.stride == 1)), "gemm: bad extra segment");

@@ -464,6 +464,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.gn_eps = d->gn_eps; a.gn_silu = d->gn_silu;
   a.act = d->act; a.sm_valid = d->sm_valid; a.img_rows = d->img_rows; a.w_img_stride = d->w_img_stride;
   a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw; a.phase2 = d->phase2;
+  a.ln_ksteps = d->ln_ksteps; a.ln_out = d->ln_out;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;

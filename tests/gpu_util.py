@@ -48,7 +48,7 @@ def pack_ups_phase(w: torch.Tensor) -> torch.Tensor:
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
-          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0):
+          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
     lib = N.load()
     d = N.GemmDesc()
@@ -64,6 +64,8 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.c0, d.c1, d.hs, d.ws, d.ho, d.wo = c0, c1, Hs, Ws, Ho, Wo
     d.ups, d.stride, d.pad, d.ks = ups, stride, (1 if ks == 3 else 0), ks
     d.phase2 = phase2
+    d.ln_ksteps = ln_ksteps
+    d.ln_out = 0 if ln_out is None else ln_out.data_ptr()
     d.M, d.N, d.K = M, Nn, K
     d.w = w_packed.data_ptr()
     d.bias = 0 if bias is None else bias.data_ptr()

@@ -588,3 +588,41 @@ def test_back_to_back_gemm_qkv(Bn, S, bm, gn):
     if Spad != S:
         assert G.vt_natural_order(vt)[:, S:].abs().max().item() == 0.0      # key padding untouched
     G.log_metric(test="b2b_qkv", B=Bn, S=S, bm=bm, q_err=eq, k_err=ek, v_err=ev)
+
+
+@pytest.mark.parametrize("M,Cc,Nn", [(128, 1280, 1280), (512, 640, 640), (64, 320, 320)])
+def test_partial_layernorm_fold_with_split_k(M, Cc, Nn):
+    """The composed feed-forward GEMM, y = LN(s) Wf^T + s Wo^T + b + x over K = 2C (sd/diffusion.py:351-381):
+    one pass (accumulators rescaled in registers at the fold boundary) and split-K with the slices ending on that boundary
+    (the rescale moves to splitk_finalize, row statistics handed over through ln_out) against fp64."""
+    g = torch.Generator().manual_seed(M + Cc)
+    s32 = torch.randn((M, Cc), generator=g) * 1.5 + 0.7
+    s16 = s32.half()
+    res = torch.randn((M, Nn), generator=g)
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    wf = torch.randn((Nn, Cc), generator=g) / math.sqrt(Cc)
+    wo = (torch.randn((Nn, Cc), generator=g) / math.sqrt(Cc)).half()
+    bias = torch.randn((Nn,), generator=g)
+    ref = (F.layer_norm(s16.double(), (Cc,), gamma.double(), beta.double(), 1e-5) @ wf.double().t() + s16.double() @ wo.double().t()
+           + bias.double() + res.double())
+    wff, gf, hf = G.ln_fold_prep(wf.to(DEV), gamma.to(DEV), beta.to(DEV), bias.to(DEV))
+    w = torch.cat([wff, wo.to(DEV)], dim=1).contiguous()
+    xf = s16.float()
+    stat = torch.stack([xf.sum(1), (xf * xf).sum(1)], dim=1).view(M, 1, 2).to(DEV)
+    s16d = s16.to(DEV).view(1, M, 1, Cc)
+    outs = {}
+    splits = [k for k in (1, 2, 4, 10) if (Cc // 64) % max(k // 2, 1) == 0 and (2 * Cc // 64) % k == 0]
+    for ksplit in splits:
+        ln_out = torch.full((M, 2), float("nan"), device=DEV)
+        out = G.igemm(s16d, w, B=1, Hs=M, Ws=1, Ho=M, Wo=1, a1=s16d, bias=hf, res=res.to(DEV), out_f32=True, ksplit=ksplit,
+                      ln_stat=stat, ln_g=gf, ln_c=Cc, ln_ksteps=Cc // 64, ln_out=ln_out)
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert err < 1.5e-2, f"ksplit {ksplit}: max abs err {err}"
+        outs[ksplit] = out
+        if ksplit > 1:
+            mean = xf.mean(1)
+            assert (ln_out[:, 0].cpu() - mean).abs().max().item() < 1e-4
+    assert len(splits) >= 2
+    for k in splits[1:]:
+        assert (outs[k] - outs[1]).abs().max().item() < 2e-3, k
