@@ -333,7 +333,9 @@ int launch(const AttnArgs& a, hipStream_t st) {
   }
   // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
   static const bool split_on = !(getenv("SDMI_ATTN_SPLIT") && atoi(getenv("SDMI_ATTN_SPLIT")) == 0);
-  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= 1024 && 2 * C::LDS <= 160 * 1024) {
+  // (at S = 4096 the split form stages four times the K/V bytes per query and loses: attention 0.646 vs 0.617 ms/step)
+  static const int split_max = getenv("SDMI_ATTN_SPLIT_MAXS") ? atoi(getenv("SDMI_ATTN_SPLIT_MAXS")) : 1024;
+  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS <= 160 * 1024) {
     dim3 grid(a.Sq / 64, a.B * a.H);
     hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS, st, a);
   } else {
