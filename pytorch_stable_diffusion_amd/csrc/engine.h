@@ -919,7 +919,9 @@ struct Engine {
     static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
     static const bool b2b_qkv_on = !(getenv("SDMI_B2B_QKV") && atoi(getenv("SDMI_B2B_QKV")) == 0);
     static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
-    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0;
+    // one round of workgroups only (<= 256 of them, 32 or 64 rows each): at 768x768 (M = 18432: 288 workgroups) the second,
+    // nearly empty round makes the fused form slower than the GEMM pairs (same box: 8.17 vs 8.11 ms/step)
+    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0 && B * S <= 16384;
     TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
     if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
