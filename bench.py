@@ -227,7 +227,7 @@ def main():
     image_latency = None
     if rank == 0 and world == 1 and not args.no_image_latency and hw == 64:
         from pytorch_stable_diffusion_amd import model_loader, pipeline
-        from tests.stub_tokenizer import StubTokenizer
+        from pytorch_stable_diffusion_amd.tokenizer import StubTokenizer
         aux = model_loader.synthetic_state_dicts(("clip", "decoder"))
         from pytorch_stable_diffusion_amd.clip import CLIP
         from pytorch_stable_diffusion_amd.vae import VAE_Decoder
@@ -276,7 +276,7 @@ def main():
             # BASELINE configs[0] end to end on the host: CLIP x2 + 20 CFG steps + VAE decode, all through the oracle
             from oracle import aux_ref
             from pytorch_stable_diffusion_amd import model_loader
-            from tests.stub_tokenizer import StubTokenizer
+            from pytorch_stable_diffusion_amd.tokenizer import StubTokenizer
             aux = model_loader.synthetic_state_dicts(("clip", "decoder"))
             tok = StubTokenizer()
             t1 = time.perf_counter()

@@ -181,7 +181,8 @@ typedef struct sdmi_gemm_desc {
   int ln_ksteps; float* ln_out;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
-/* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch */
+/* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch; iters < 0: -iters launches
+ * timed one by one with the L2s evicted before each (64 MiB fill), minimum returned */
 int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream);
 /* Back-to-back GEMM of the 320-channel attention blocks (csrc/b2b.hip; sd/diffusion.py:321-363): S = a1 w1^T + b1 + r1, then
  * Y = cscale * (LN0(S) w2'^T + h2) [partial = 0, K2 = 320] or Y = LN0(S) w2a'^T + S w2b^T + h2 + r2 [partial = 1, K2 = 640,

@@ -325,11 +325,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 template <int D>
 int launch(const AttnArgs& a, hipStream_t st) {
   typedef ACfg<D> C;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[16] = {};            // the dynamic-LDS attribute is per device
+  int dev = 0;
+  SDMI_CHECK_HIP(hipGetDevice(&dev));
+  SDMI_REQUIRE(dev >= 0 && dev < 16, "attention: device index %d out of range", dev);
+  if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS));
-    attr_done = true;
+    attr_done[dev] = true;
   }
   // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
   static const bool split_on = !(getenv("SDMI_ATTN_SPLIT") && atoi(getenv("SDMI_ATTN_SPLIT")) == 0);

@@ -556,10 +556,13 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
 template <int BM>
 int launch_b2b(const B2bArgs& a, hipStream_t st) {
   typedef B2bCfg<BM> Cf;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[16] = {};            // the dynamic-LDS attribute is per device
+  int dev = 0;
+  SDMI_CHECK_HIP(hipGetDevice(&dev));
+  SDMI_REQUIRE(dev >= 0 && dev < 16, "b2b: device index %d out of range", dev);
+  if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
-    attr_done = true;
+    attr_done[dev] = true;
   }
   hipLaunchKernelGGL(b2b_kernel<Cf>, dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
   SDMI_CHECK_HIP(hipGetLastError());

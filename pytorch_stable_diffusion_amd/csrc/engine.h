@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -97,6 +98,7 @@ struct PlanStore {
   std::map<ShapeKey, std::pair<std::string, std::pair<int, float>>> table;   // key -> (cfg name, (ksplit, us))
   std::string cache_path;
   bool loaded = false;
+  std::mutex mu;      // the store is process-wide; handles on several devices / threads read and append concurrently (ctypes drops the GIL)
 
   static std::string lib_path() {
     Dl_info info;
@@ -130,6 +132,7 @@ struct PlanStore {
     fclose(f);
   }
   void load() {
+    std::lock_guard<std::mutex> lk(mu);
     if (loaded) return;
     loaded = true;
     const std::string lib = lib_path();
@@ -150,7 +153,16 @@ struct PlanStore {
     }
     read_file(cache_path);            // the user's own tuning wins over the shipped table
   }
+  // copy of the stored plan for `k` (false: none)
+  bool lookup(const ShapeKey& k, std::string* name, int* ksplit, float* us) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find(k);
+    if (it == table.end()) return false;
+    *name = it->second.first; *ksplit = it->second.second.first; *us = it->second.second.second;
+    return true;
+  }
   void append(const ShapeKey& k, const char* name, int ksplit, float us) {
+    std::lock_guard<std::mutex> lk(mu);
     table[k] = {name, {ksplit, us}};
     if (cache_path.empty()) return;
     FILE* f = fopen(cache_path.c_str(), "a");
@@ -255,6 +267,28 @@ struct Engine {
   Engine() { (void)hipGetDevice(&device); }
   ~Engine() {
     for (void* p : owned) (void)hipFree(p);
+    for (void* p : ctx_owned) (void)hipFree(p);
+  }
+  // buffers sized by the context batch (sdmi_unet_set_context): released and re-made when the batch changes
+  std::vector<void*> ctx_owned;
+  void free_ctx() {
+    for (void* p : ctx_owned) (void)hipFree(p);
+    ctx_owned.clear();
+    ctx16 = nullptr;
+    ctxK.clear(); ctxVt.clear();
+    xfW1.clear(); xfW2.clear(); xfG.clear(); xfH.clear();
+    xf_km = xf_vm = xf_vp = nullptr; xf_kq = nullptr;
+  }
+  template <class T>
+  int dmalloc_ctx(T** out, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+      sdmi_set_error("hipMalloc(%zu) failed", bytes);
+      return SDMI_ENOMEM;
+    }
+    ctx_owned.push_back(p);
+    *out = (T*)p;
+    return SDMI_OK;
   }
 
   // Every entry point that launches work calls this first: the handle's memory lives on `device`, and a launch
@@ -507,13 +541,18 @@ struct Engine {
       if (tune) {
         PlanStore& ps = plan_store();
         ps.load();
-        auto st_it = ps.table.find(key);
         bool have = false;
-        if (st_it != ps.table.end()) {          // stored plan: valid only if this build still has the config
+        std::string st_name;
+        int st_ks = 1;
+        float st_us = 0.f;
+        if (ps.lookup(key, &st_name, &st_ks, &st_us)) {          // stored plan: valid only if this build still has the config ...
           for (int c = 0; c < sdmi_gemm_num_cfgs() && !have; ++c)
-            if (st_it->second.first == sdmi_gemm_cfg_name(c) && sdmi_gemm_cfg_applicable(a, c)) {
-              pl.cfg = c; pl.ksplit = st_it->second.second.first; pl.us = st_it->second.second.second; have = true;
+            if (st_name == sdmi_gemm_cfg_name(c) && sdmi_gemm_cfg_applicable(a, c)) {
+              pl.cfg = c; pl.ksplit = st_ks; pl.us = st_us; have = true;
             }
+          // ... and its split-K is one the tuner itself could have chosen for this engine: the slabs must fit (the table is
+          // shared by engines with different slab sizes, and a hand-edited line must not write past the slab)
+          if (have && !ksplit_ok(a, pl.cfg, pl.ksplit)) have = false;
         }
         if (!have) {
           TRY(tune_gemm(a, &pl));
@@ -546,7 +585,8 @@ struct Engine {
     }
     it->second.calls += 1;
     it->second.flops = 2.0 * a.M * a.N * a.K;
-    const int nl = a.ksplit > 1 ? 2 : 1;
+    const bool inred = sdmi_gemm_cfg_inred(it->second.cfg) != 0;     // split-K partials combined inside the launch
+    const int nl = (a.ksplit > 1 && !inred) ? 2 : 1;
     prof_begin(0, 2.0 * a.M * a.N * a.K);
     TRY(sdmi_launch_gemm(a, it->second.cfg, st));
     prof_end();
@@ -557,7 +597,7 @@ struct Engine {
       log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
                  a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.ksplit, 2.0 * a.M * a.N * a.K,
                  2.0 * a.N * a.K, a.out_f32, a.res != nullptr);
-      if (a.ksplit > 1) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
+      if (a.ksplit > 1 && !inred) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
     }
     return SDMI_OK;
   }
@@ -577,6 +617,21 @@ struct Engine {
     }
   }
 
+  // the tuner's admission rule for a split-K factor (also applied to plans read from a table)
+  bool ksplit_ok(const GemmArgs& a0, int cfg, int ks) const {
+    if (ks < 1 || ks > 16) return false;
+    if (ks == 1) return true;
+    int bm, bn;
+    sdmi_gemm_cfg_dims(cfg, &bm, &bn);
+    const int nkt = a0.K / 64;
+    const int tiles = ((a0.M + bm - 1) / bm) * ((a0.N + bn - 1) / bn);
+    if (tiles * ks > 1024 || nkt / ks < 4) return false;
+    if ((size_t)ks * a0.M * a0.N * 4 > slab_bytes) return false;
+    if (a0.ln_stat && !(a0.ln_ksteps > 0 && a0.ln_out && nkt % ks == 0 && a0.ln_ksteps % (nkt / ks) == 0 && cfg < sdmi_gemm_num_plain_cfgs())) return false;
+    if ((a0.img_rows && !a0.phase2) || a0.act == 2) return false;       // these epilogues live in the one-pass path only
+    return true;
+  }
+
   static constexpr size_t kThrashBytes = (size_t)64 << 20;
   char* thrash = nullptr;
   int tune_gemm(const GemmArgs& a0, Plan* best) {
@@ -585,18 +640,11 @@ struct Engine {
     SDMI_CHECK_HIP(hipEventCreate(&e0));
     SDMI_CHECK_HIP(hipEventCreate(&e1));
     float best_us = 1e30f;
-    const int nkt = a0.K / 64;
     for (int cfg = 0; cfg < sdmi_gemm_num_cfgs(); ++cfg) {
-      int bm, bn;
-      sdmi_gemm_cfg_dims(cfg, &bm, &bn);
       if (!sdmi_gemm_cfg_applicable(a0, cfg)) continue;
-      const int tiles = ((a0.M + bm - 1) / bm) * ((a0.N + bn - 1) / bn);
-      for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
-        if (ks > 1 && (tiles * ks > 1024 || nkt / ks < 4)) continue;
-        if (ks > 1 && (size_t)ks * a0.M * a0.N * 4 > slab_bytes) continue;
-        if (ks > 1 && a0.ln_stat &&
-            !(a0.ln_ksteps > 0 && a0.ln_out && nkt % ks == 0 && a0.ln_ksteps % (nkt / ks) == 0 && cfg < sdmi_gemm_num_plain_cfgs())) continue;
-        if (ks > 1 && ((a0.img_rows && !a0.phase2) || a0.act == 2)) continue;   // these epilogues live in the one-pass path only
+      for (int ks : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
+        if (!ksplit_ok(a0, cfg, ks)) continue;
+        if (ks == 1 && sdmi_gemm_cfg_inred(cfg)) continue;               // the "...r" twin only differs when K is split
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;

@@ -238,16 +238,17 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
   SDMI_REQUIRE(batch >= 1 && batch <= 16 && n_tokens >= 1 && n_tokens <= kCtxPad, "set_context: batch=%d tokens=%d unsupported (tokens <= %d)", batch, n_tokens, kCtxPad);
   TRY(u->enter(stream));
   if (u->ctx_batch != batch || !u->ctx16) {
-    TRY(u->dmalloc(&u->ctx16, (size_t)batch * kCtxPad * kCtx * 2));
-    u->ctxK.clear();
-    u->ctxVt.clear();
-    u->xfW1.clear(); u->xfW2.clear(); u->xfG.clear(); u->xfH.clear();
+    // per-batch buffers: the previous set is released (hipFree waits for work in flight), and ctx_batch stays 0 until the
+    // new set is complete, so a failure half way cannot be mistaken for a usable context by the next call
+    u->ctx_batch = 0;
+    u->free_ctx();
+    TRY(u->dmalloc_ctx(&u->ctx16, (size_t)batch * kCtxPad * kCtx * 2));
     int cmax = 0;
     for (const std::string& p : u->attn_order) {
       const AttnW& w = u->attn[p];
       f16 *k, *v;
-      TRY(u->dmalloc(&k, (size_t)batch * kCtxPad * w.C * 2));
-      TRY(u->dmalloc(&v, (size_t)batch * w.C * kCtxVtLd * 2));
+      TRY(u->dmalloc_ctx(&k, (size_t)batch * kCtxPad * w.C * 2));
+      TRY(u->dmalloc_ctx(&v, (size_t)batch * w.C * kCtxVtLd * 2));
       SDMI_CHECK_HIP(hipMemsetAsync(v, 0, (size_t)batch * w.C * kCtxVtLd * 2, u->st));
       u->ctxK.push_back(k);
       u->ctxVt.push_back(v);
@@ -255,20 +256,20 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
       float *g = nullptr, *h = nullptr;
       if (w.wqT) {
         const size_t rows = (size_t)batch * Engine::kXfCols;
-        TRY(u->dmalloc(&w1, rows * w.C * 2));
-        TRY(u->dmalloc(&w2, rows * w.C * 2));
-        TRY(u->dmalloc(&g, rows * 4));
-        TRY(u->dmalloc(&h, rows * 4));
+        TRY(u->dmalloc_ctx(&w1, rows * w.C * 2));
+        TRY(u->dmalloc_ctx(&w2, rows * w.C * 2));
+        TRY(u->dmalloc_ctx(&g, rows * 4));
+        TRY(u->dmalloc_ctx(&h, rows * 4));
         cmax = w.C > cmax ? w.C : cmax;
       }
       u->xfW1.push_back(w1); u->xfW2.push_back(w2); u->xfG.push_back(g); u->xfH.push_back(h);
     }
     if (cmax) {
       const size_t rows = (size_t)batch * Engine::kXfCols;
-      TRY(u->dmalloc(&u->xf_km, rows * cmax * 2));
-      TRY(u->dmalloc(&u->xf_vm, rows * cmax * 2));
-      TRY(u->dmalloc(&u->xf_vp, (size_t)batch * kCtxPad * cmax * 2));
-      TRY(u->dmalloc(&u->xf_kq, rows * cmax * 4));
+      TRY(u->dmalloc_ctx(&u->xf_km, rows * cmax * 2));
+      TRY(u->dmalloc_ctx(&u->xf_vm, rows * cmax * 2));
+      TRY(u->dmalloc_ctx(&u->xf_vp, (size_t)batch * kCtxPad * cmax * 2));
+      TRY(u->dmalloc_ctx(&u->xf_kq, rows * cmax * 4));
     }
   }
   SDMI_CHECK_HIP(hipMemsetAsync(u->ctx16, 0, (size_t)batch * kCtxPad * kCtx * 2, u->st));
@@ -356,6 +357,7 @@ int sdmi_cfg_ddpm_step(const float* eps_dev, int do_cfg, float cfg_scale, float*
 int sdmi_unet_denoise_step(sdmi_unet* u, float* latents_dev, int step_idx, int do_cfg, float cfg_scale,
                            const float* noise_dev, const float* coef, int h, int w, void* stream) {
   if (!u) { sdmi_set_error("denoise_step: null handle"); return SDMI_EINVAL; }
+  TRY(u->enter(stream));             // before any allocation: eps_buf must live on the handle's device
   const int batch = do_cfg ? 2 : 1;
   const size_t need = (size_t)batch * 4 * h * w;
   if (u->eps_elems < need) {
@@ -470,14 +472,36 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.zero = g_zero; a.slab = g_slab;
   return sdmi_launch_gemm(a, d->cfg, (hipStream_t)stream);
 }
-// Micro-benchmark: `iters` back-to-back launches bracketed by two HIP events on `stream`.
+// Micro-benchmark: `iters` back-to-back launches bracketed by two HIP events on `stream`; iters < 0: -iters launches timed one
+// by one, each behind a 64 MiB fill that evicts the eight L2s (the state a GEMM finds inside the denoising step: csrc/engine.h
+// tune_gemm), minimum returned.
 int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream) {
-  if (!d || !us_per_iter || iters < 1) { sdmi_set_error("bench_gemm: bad arguments"); return SDMI_EINVAL; }
+  if (!d || !us_per_iter || iters == 0) { sdmi_set_error("bench_gemm: bad arguments"); return SDMI_EINVAL; }
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;
   SDMI_CHECK_HIP(hipEventCreate(&e0));
   SDMI_CHECK_HIP(hipEventCreate(&e1));
   TRY(sdmi_op_gemm(d, stream));
+  if (iters < 0) {
+    static char* thrash = nullptr;
+    const size_t kThrash = (size_t)64 << 20;
+    if (!thrash) SDMI_CHECK_HIP(hipMalloc((void**)&thrash, kThrash));
+    float best = 1e30f;
+    for (int i = 0; i < -iters; ++i) {
+      SDMI_CHECK_HIP(hipMemsetAsync(thrash, i, kThrash, st));
+      SDMI_CHECK_HIP(hipEventRecord(e0, st));
+      TRY(sdmi_op_gemm(d, stream));
+      SDMI_CHECK_HIP(hipEventRecord(e1, st));
+      SDMI_CHECK_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      SDMI_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (ms * 1e3f < best) best = ms * 1e3f;
+    }
+    *us_per_iter = best;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SDMI_OK;
+  }
   SDMI_CHECK_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i) TRY(sdmi_op_gemm(d, stream));
   SDMI_CHECK_HIP(hipEventRecord(e1, st));

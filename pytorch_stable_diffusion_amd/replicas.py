@@ -229,16 +229,8 @@ def _main(argv=None) -> int:
     if not prompts:
         raise SystemExit("replicas: empty prompts file")
     if args.stub_tokenizer:
-        import zlib
-
-        class _Tok:      # duck-typed batch_encode_plus (sd/pipeline.py:109)
-            def batch_encode_plus(self, texts, padding=None, max_length=77):
-                rows = []
-                for t in texts:
-                    ids = [49406] + [320 + zlib.crc32(w.encode()) % 40000 for w in t.split()][: max_length - 2] + [49407]
-                    rows.append(ids + [49407] * (max_length - len(ids)))
-                return type("Enc", (), {"input_ids": rows})()
-        tokenizer = _Tok()
+        from .tokenizer import StubTokenizer
+        tokenizer = StubTokenizer()
     else:
         if not (args.vocab and args.merges):
             ap.error("--vocab and --merges are required unless --stub-tokenizer")

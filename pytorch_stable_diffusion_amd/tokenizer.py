@@ -152,3 +152,19 @@ class CLIPTokenizer:
         return Encoding(input_ids=rows, attention_mask=mask)
 
     __call__ = batch_encode_plus
+
+
+class StubTokenizer:
+    """Duck-typed stand-in for CLIPTokenizer when vocab.json / merges.txt are not available (benchmarks, tests, the
+    replicas launcher's --stub-tokenizer): ``batch_encode_plus([text], padding="max_length", max_length=77).input_ids``
+    as sd/pipeline.py:109 calls it; word ids are CRC32 hashes, so equal prompts give equal ids in every process."""
+    BOS, EOS = 49406, 49407
+
+    def batch_encode_plus(self, texts, padding=None, max_length=77, **_unused) -> Encoding:
+        import zlib
+        rows = []
+        for t in texts:
+            words = [320 + (zlib.crc32(w.encode()) % 40000) for w in t.split()][: max_length - 2]
+            ids = [self.BOS] + words + [self.EOS]
+            rows.append(ids + [self.EOS] * (max_length - len(ids)))
+        return Encoding(input_ids=rows, attention_mask=[[1] * len(r) for r in rows])

@@ -15,6 +15,23 @@ def seeded(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g, dtype=torch.float32) * scale
 
 
+def stress_input(shape, seed):
+    """NCHW block input for the stress-law fixtures (tests/golden/make_golden_stress.py): N(0,1) times a per-channel scale
+    spread over two decades with 1 % outlier channels (synth.stress_row_scale, x3), plus a per-channel offset of up to
+    +-2 scales -- so token rows carry outlier channels and a mean of several sigma."""
+    C = shape[1]
+    cs = synth.stress_row_scale(f"input#{seed}", C) * 3.0
+    g = torch.Generator(device="cpu").manual_seed(seed + 100000)
+    co = (torch.rand(C, generator=g) * 4.0 - 2.0) * cs
+    return seeded(shape, seed) * cs.view(1, C, 1, 1) + co.view(1, C, 1, 1)
+
+
+def stress_block_weights(prefix):
+    man = arch.diffusion_manifest()
+    sub = {k: v for k, v in man.items() if k.startswith(prefix + ".")}
+    return synth.synth_state_dict(sub, law="stress")
+
+
 def load_npz(name):
     return np.load(os.path.join(GOLDEN, name))
 

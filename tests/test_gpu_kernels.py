@@ -29,9 +29,16 @@ def test_library_loaded_is_in_tree():
 def _plain_cfgs():
     from pytorch_stable_diffusion_amd import _native as N
     lib = N.load()
-    # "h..." (halo-reuse), "g..." (fused GroupNorm) and the 160-wide tiles are 3x3-conv configs with their own tests
+    # "h..." / "k..." (halo-reuse), "g..." (fused GroupNorm) and the 160-wide tiles are 3x3-conv configs with their own tests
     names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
-    return [i for i, nm in enumerate(names) if nm[0] not in "hg" and "x160" not in nm]
+    return [i for i, nm in enumerate(names) if nm[0] not in "hgk" and "x160" not in nm]
+
+
+def _k_cfgs():
+    """the general halo kernel (csrc/gemm.hip conv_halo2_kernel): "k<BM>x<BN>s<NS>", "...r" = split-K combined in the launch"""
+    lib = N_.load()
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    return [i for i, nm in enumerate(names) if nm[0] == "k"]
 
 
 @pytest.mark.parametrize("cfg", _plain_cfgs())
@@ -89,6 +96,9 @@ def _conv_ref(x_nhwc, w_oihw, stride, ups):
     dict(B=1, H=64, W=64, C0=64, C1=64, Co=192, ks=3, stride=1, ups=0),      # halo-reuse kernels, concat, W=64
     dict(B=2, H=32, W=32, C0=128, C1=0, Co=64, ks=3, stride=1, ups=0),       # halo-reuse, W=32
     dict(B=2, H=8, W=8, C0=128, C1=0, Co=128, ks=3, stride=1, ups=0),        # halo-reuse, 8x8 map (one image per tile)
+    dict(B=4, H=8, W=8, C0=192, C1=64, Co=160, ks=3, stride=1, ups=0),       # 8x8 maps: two whole images per 128-row tile, concat
+    dict(B=2, H=16, W=16, C0=256, C1=0, Co=320, ks=3, stride=1, ups=0),      # 16x16, N = 320 (160-wide tiles)
+    dict(B=1, H=16, W=16, C0=128, C1=0, Co=80, ks=3, stride=1, ups=1),       # x2-upsampled input through the halo kernels
 ])
 def test_conv_implicit_gemm(case):
     c = case
@@ -101,9 +111,10 @@ def test_conv_implicit_gemm(case):
     ref = _conv_ref(xin, w, c["stride"], c["ups"])
     Ho, Wo = ref.shape[1], ref.shape[2]
     wp = G.pack_conv(w.to(DEV))
-    n_halo = 0
+    n_halo = n_k = 0
+    kset = set(_k_cfgs())
     for cfg in [-1] + _cfgs():
-        for ksplit in (1, 3):
+        for ksplit in (1, 3, 4) if cfg in kset else (1, 3):
             try:
                 out = G.igemm(x0.to(DEV), wp, B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"],
                               ups=c["ups"], a1=None if x1 is None else x1.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit)
@@ -111,11 +122,13 @@ def test_conv_implicit_gemm(case):
                 assert "not applicable" in str(exc) or "LDS" in str(exc), exc
                 continue
             n_halo += cfg >= 0 and N_.load().sdmi_gemm_config_name(cfg).decode()[0] == "h"
+            n_k += cfg in kset
             err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
             G.log_metric(test="conv", case=str(c), cfg=cfg, ksplit=ksplit, max_abs_err=err)
             assert err < 2e-3, f"{c} cfg {cfg} ksplit {ksplit}: max abs err {err}"
     if c["ks"] == 3 and c["stride"] == 1 and c["W"] << c["ups"] in (8, 16, 32, 64):
-        assert n_halo > 0, "no halo-reuse config ran on an eligible conv"
+        assert n_halo > 0 or c["B"] * (c["H"] << c["ups"]) * (c["W"] << c["ups"]) % 128, "no halo-reuse config ran on an eligible conv"
+        assert n_k > 0 or (c["B"] * (c["H"] << c["ups"]) * (c["W"] << c["ups"])) % 128, "the general halo kernel did not run on an eligible conv"
 
 
 @pytest.mark.parametrize("X0,X1,H,W", [(64, 0, 16, 16), (128, 64, 12, 12), (192, 128, 8, 8)])
@@ -132,19 +145,23 @@ def test_conv_with_fused_skip_segment(X0, X1, H, W):
     xs = x0 if x1 is None else torch.cat([x0, x1], -1)
     ref = _conv_ref(t, w3, 1, 0) + _conv_ref(xs, ws, 1, 0)
     wp = torch.cat([G.pack_conv(w3.to(DEV)), G.pack_conv(ws.to(DEV))], 1).contiguous()
-    ran = 0
+    ran = ran_k = 0
+    kset = set(_k_cfgs())
     for cfg in [-1] + _cfgs():
         for ksplit in (1, 2, 5):
             try:
                 out = G.igemm(t.to(DEV), wp, B=B, Hs=H, Ws=W, Ho=H, Wo=W, ks=3, out_f32=True, cfg=cfg, ksplit=ksplit,
                               x0=x0.to(DEV), x1=None if x1 is None else x1.to(DEV))
-            except ValueError as exc:       # halo-reuse kernels do not take the extra segment
+            except ValueError as exc:       # the first-generation halo kernels do not take the extra segment
                 assert "not applicable" in str(exc) or "LDS" in str(exc), exc
                 continue
             ran += 1
+            ran_k += cfg in kset
             err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
             assert err < 2e-3, f"cfg {cfg} ksplit {ksplit}: max abs err {err}"
     assert ran >= 3 * len(_plain_cfgs())
+    if W in (8, 16):
+        assert ran_k >= 3, "the general halo kernel did not take the fused skip segment"
 
 
 def test_gemm_transposed_tail():
@@ -446,19 +463,24 @@ def test_upsample_conv_as_four_phase_convs(Bn, Hs, Ws, Cin, Cout, ksplit):
     nine = G.igemm(x.to(DEV), G.pack_conv(w.to(DEV)), B=Bn, Hs=Hs, Ws=Ws, Ho=2 * Hs, Wo=2 * Ws, ks=3, ups=1, bias=bias.to(DEV), out_f32=True)
     e9 = (nine.cpu().double() - ref).abs().max().item()
     rows = Bn * Hs * Ws
-    n_run = 0
-    for pc in _plain_cfgs():
+    n_run = n_k = 0
+    for pc in _plain_cfgs() + _k_cfgs():
         bm = G.gemm_tile(pc)[0]
         if rows % bm:
             continue
-        out = torch.full((4 * rows, Cout), float("nan"), device=DEV)
-        got = G.igemm(x.to(DEV), w4, B=Bn, Hs=Hs, Ws=Ws, Ho=Hs, Wo=Ws, ks=2, bias=bias.to(DEV), out_f32=True, cfg=pc, ksplit=ksplit,
-                      phase2=1, img_rows=rows, w_img_stride=Cout * 4 * Cin, n_out=Cout)
-        del out
+        try:
+            got = G.igemm(x.to(DEV), w4, B=Bn, Hs=Hs, Ws=Ws, Ho=Hs, Wo=Ws, ks=2, bias=bias.to(DEV), out_f32=True, cfg=pc, ksplit=ksplit,
+                          phase2=1, img_rows=rows, w_img_stride=Cout * 4 * Cin, n_out=Cout)
+        except ValueError as exc:
+            assert pc in _k_cfgs() and ("not applicable" in str(exc) or "LDS" in str(exc)), exc
+            continue
         err = (got.cpu().double() - ref).abs().max().item()
         assert err < max(2 * e9, 4e-3), f"cfg {pc}: max abs err {err} (9-tap path: {e9})"
         n_run += 1
+        n_k += pc in _k_cfgs()
     assert n_run >= 8
+    if Ws % 8 == 0 and rows % 128 == 0:
+        assert n_k > 0, "the general halo kernel did not run the phase-decomposed upsample conv"
     G.log_metric(test="ups_phase", rows=rows, C=Cin, nine_tap_err=e9)
 
 
