@@ -239,6 +239,12 @@ int sdmi_op_attention(const void* q, int ldq, const void* k, int ldk, int k_batc
 /* GroupNorm(32) over NHWC (optionally two concat sources), fp16 out; LayerNorm over rows. */
 int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P,
                       const float* gamma, const float* beta, float eps, int silu, void* y_f16, void* stream);
+/* GroupNorm(32)(+SiLU) of x = sum_z slab[z][B*P][C] + bias[C] (+ res[B*P][C]), slabs added in order: the split-K combine of a conv
+ * (sd/diffusion.py:179, 205) and the GroupNorm that follows it (:199, :294) in one launch.  P <= 1024, (C/32) % 4 == 0.
+ * out32 / out16 (optional): copies of x for other readers. */
+int sdmi_op_groupnorm_slab(const float* slab, int ksplit, const float* bias, const void* res, int res_f32, int C, int B, int P,
+                           const float* gamma, const float* beta, float eps, int silu, void* y_f16, float* out32, void* out16,
+                           void* stream);
 int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,
                       void* y_f16, void* stream);
 /* GroupNorm statistics only: per (image, pixel chunk, group) partial {sum, sum of squares} into partial_out

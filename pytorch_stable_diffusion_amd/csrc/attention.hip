@@ -43,6 +43,10 @@ struct ACfg {
   static constexpr int V_INST = DP / 8;
   static constexpr int STAGE = K_BYTES + V_BYTES;
   static constexpr bool LROW = DP > D;             // a spare V^T row exists (d = 40, 80): row sums come from the MFMA
+  // d = 40: the last k16 step of QK^T covers head-dim columns 32..47, of which 40..47 are padding (zeros on the Q side).
+  // The running-max bias (K side 1, Q side -m_run) rides in column 40 instead of a k16 step of its own: 6 instead of 8
+  // MFMAs per 64-key tile in the S = 4096 self-attention.
+  static constexpr bool SPARE = (D % 16) != 0;
   static constexpr int LDS = 2 * STAGE;
 };
 
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   f16x8 kbias, qbias;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { kbias[e] = (f16)0.f; qbias[e] = (f16)0.f; }
-  if (h == 0) kbias[0] = (f16)1.f;
+  // SPARE: k-index 40 is element 0 of the half-wave h = 1 in the last k16 step; otherwise k-index 0 of the extra step (h = 0)
+  if (h == (C::SPARE ? 1 : 0)) kbias[0] = (f16)1.f;
 
   // one 64-key tile: S'^T = K Q'^T - m_run, online softmax, O^T += V^T P^T.  FIRST: tile 0 (m_run not set yet).
   auto tile_body = [&](auto masked_tag, auto first_tag, int t, int cur) {
@@ -174,10 +179,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) {
-        const f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r) * (D * 2) + koff[s]);
+        f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r) * (D * 2) + koff[s]);
+        if (C::SPARE && s == C::NS - 1 && h == 1) kf = kbias;       // padding columns of K: {1, 0, ...} against Q's {-m_run, 0, ...}
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
-      if constexpr (!FIRST) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kbias, qbias, sacc[kb], 0, 0, 0);
+      if constexpr (!FIRST && !C::SPARE) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kbias, qbias, sacc[kb], 0, 0, 0);
     }
     if constexpr (MASKED) {   // keys beyond Skv (ragged last tile) and, for causal attention, keys after the query
       const int kbase_i = t * 64 + 4 * h;
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[kb][e] -= de;
       m_run = m_new;
-      qbias[0] = h == 0 ? (f16)(-m_run) : (f16)0.f;
+      if constexpr (C::SPARE) { if (h == 1) qf[C::NS - 1][0] = (f16)(-m_run); }
+      else qbias[0] = h == 0 ? (f16)(-m_run) : (f16)0.f;
     }
     float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll

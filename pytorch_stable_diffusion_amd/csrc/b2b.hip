@@ -336,10 +336,12 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
 #pragma unroll
       for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); b1 += __shfl_xor(b1, o); }
       // statistics of the fp16 values the second product multiplies (as the row-statistics epilogue of gemm.hip)
-      const float mean = a1 * (1.f / kC);
-      float var = b1 * (1.f / kC) - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      const float rstd = rsqrtf(var + p.eps);
+      // the variance E[x^2] - E[x]^2 in fp64: one cancellation per row, (mean/sigma)^2 ulps of fp32 otherwise
+      const double mean_d = (double)a1 * (1.0 / kC);
+      double var_d = (double)b1 * (1.0 / kC) - mean_d * mean_d;
+      var_d = var_d < 0.0 ? 0.0 : var_d;
+      const float mean = (float)mean_d;
+      const float rstd = rsqrtf((float)var_d + p.eps);
 #pragma unroll
       for (int i = 0; i < kNR; ++i) {                    // the lanes holding row i of this wave: its index in lane bits 5.. down
         const int src = kNR == 8 ? (((i >> 2) << 5) | (((i >> 1) & 1) << 4) | ((i & 1) << 3)) : (((i >> 1) << 5) | ((i & 1) << 4));

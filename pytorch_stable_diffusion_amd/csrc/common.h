@@ -119,19 +119,12 @@ struct GemmArgs {
   // ([B][gn_nchunk][32][2]), reduced in the conv's prologue; y = silu(x * (rstd gamma) + (beta - mean rstd gamma)) is
   // applied once per staged halo chunk in LDS, and the 9 taps read the normalised image.  nullptr: plain conv.
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
-  // conv_halo2_kernel only (set by the launcher): K-slice z of a split-K launch owns channel chunks [csplit[z], csplit[z+1])
-  // (a chunk = 64 input channels x all taps, or 64 channels of the fused 1x1 skip segment);
-  // inred = 1: the partial tiles are combined INSIDE the launch -- every K-slice workgroup draws a ticket from
-  // tile_cnt[2*tile]; all but the last write their fp32 tile to the slab with write-through stores and count themselves
-  // done in tile_cnt[2*tile+1]; the workgroup that drew the last ticket waits for them, adds the slabs to its own tile in
-  // slab order (bit-identical to splitk_finalize) and runs the ordinary epilogue.  No finalize launch, ksplit-1 instead of
-  // ksplit slab writes.  The counters are zero between launches (the last arriver resets them).
-  short csplit[18];
-  int inred;
-  int* tile_cnt;
+  int no_finalize;     // split-K: leave the partial sums in the slabs, launch no splitk_finalize
 };
 
-int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st);   // cfg < 0: heuristic
+// cfg < 0: heuristic.  ksplit_out: effective split-K factor of the launch.  a.no_finalize = 1: a split-K launch only writes
+// its slabs (the caller combines them, e.g. sdmi_launch_groupnorm with GnArgs::slab)
+int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out = nullptr);
 
 // Back-to-back GEMM of the 320-channel attention blocks (b2b.hip): S = A1 W1^T + b1 + R1, then the next Linear with the
 // LayerNorm of S folded in, in one launch.  All matrices have 320 columns / output rows.
@@ -163,7 +156,6 @@ int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 /
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
 int sdmi_gemm_num_plain_cfgs(void);   // configs [0, n) are igemm_kernel tiles; the rest are halo-reuse conv kernels
-int sdmi_gemm_cfg_inred(int cfg);     // 1: this config combines its split-K partials inside the launch (no finalize launch)
 void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn);
 bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg);
 size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int cfg, int ksplit);
@@ -198,6 +190,11 @@ struct GnArgs {
   f16* y;                            // [B*P][C0+C1]
   float* partial;                    // scratch: [B][nchunk][32][2]
   int nchunk;
+  // slab != nullptr (single-launch kernel only, C1 = 0): the input is NOT a tensor but the split-K partial sums of the
+  // producing GEMM, x = sum_z slab[z][m][c] + sbias[c] (+ sres[m][c]) added in slab order exactly like splitk_finalize --
+  // the finalize launch of a split-K conv and the GroupNorm that follows it (sd/diffusion.py:179 -> 199) as ONE kernel.
+  // sout / sout16 (optional) receive x itself (fp32 / fp16 [B*P][C]) when another consumer needs the conv's output.
+  const float* slab; int ksplit; const float* sbias; const void* sres; int sres_f32; float* sout; f16* sout16;
 };
 int sdmi_gn_nchunk(int P);
 int sdmi_gn_launches(const GnArgs& a);

@@ -227,6 +227,33 @@ struct Engine {
   int tuned_shapes = 0;       // shapes this handle had to time itself (not found in the plan store)
   int launches = 0;
   hipStream_t st = nullptr;
+  // Deferred split-K combine.  A split-K conv whose only consumer is a GroupNorm the single-launch kernel takes (maps up to
+  // 32x32: conv_feature -> groupnorm_merged inside every ResBlock, conv_merged -> the following attention block's GroupNorm;
+  // sd/diffusion.py:179 -> 199, 205 -> 294) leaves its partial sums in the slabs; that GroupNorm adds them up itself
+  // (GnArgs::slab) and writes the conv's output on the side when somebody else needs it.  One launch and one round trip of
+  // the tensor less per pair.  `pend` is checked by EVERY launch helper: whoever comes next and is not that GroupNorm gets
+  // the ordinary splitk_finalize first (flush_pending), so the deferral can never be observed.
+  bool pend = false;
+  bool pend_keep16 = false;            // the deferred conv's fp16-only output has a reader besides the GroupNorm
+  GemmArgs pend_args;
+  const void* pend_key = nullptr;      // output pointer of the deferred conv
+  static bool defer_on() { static const bool on = !(getenv("SDMI_FIN_GN") && atoi(getenv("SDMI_FIN_GN")) == 0); return on; }
+  // Largest map (pixels) on which the combine is deferred.  Measured on one MI355X (rocprofv3 per shape, same box,
+  // gpurun_out/r3i_A vs r3i_B): the 64-workgroup GroupNorm that also adds the slabs costs 8.3 us at 8x8 (splitk_finalize 4.7 +
+  // GroupNorm 4.6 before), 11 - 17 us at 16x16 (12 - 14 before) and 20 - 29 us at 32x32 (16 - 20 before: 80-byte pieces of
+  // 3 - 6 slabs through 64 CUs); with every eligible pair deferred the step has 27 launches fewer and is 1.4 % SLOWER
+  // (234.0 vs 237.3 steps/s, two interleaved runs each).  Default: 8x8 maps only.
+  static int defer_max_px() { static const int v = getenv("SDMI_FIN_GN_MAXPX") ? atoi(getenv("SDMI_FIN_GN_MAXPX")) : 64; return v; }
+  int flush_pending() {
+    if (!pend) return SDMI_OK;
+    pend = false;
+    prof_begin(2, 0.0);
+    TRY(sdmi_launch_splitk_finalize(pend_args, st));
+    prof_end();
+    launches += 1;
+    log_launch("finalize M=%d N=%d K=%d split=%d", pend_args.M, pend_args.N, pend_args.K, pend_args.ksplit);
+    return SDMI_OK;
+  }
   // optional per-launch HIP-event profiling (bench roofline): class 0 = igemm, 1 = attention, 2 = other
   bool profiling = false;
   struct ProfRec { hipEvent_t e0, e1; int cls; double flops; };
@@ -566,10 +593,15 @@ struct Engine {
     return SDMI_OK;
   }
 
-  int gemm(GemmArgs a, RowStat* rs = nullptr) {
+  // defer: a split-K launch leaves its partial sums in the slabs for the GroupNorm that follows (see `pend`)
+  int gemm(GemmArgs a, RowStat* rs = nullptr, bool defer = false) {
+    TRY(flush_pending());
     std::map<ShapeKey, Plan>::iterator it;
     TRY(plan_of(a, &it));
     a.ksplit = it->second.ksplit;
+    defer = defer && defer_on() && a.ksplit > 1 && !a.outT && !a.act && !a.phase2 && a.cs_hi == 0 && !a.ln_stat && !a.rowstat &&
+            a.ldc == a.N && (!a.res || a.ldr == a.N) && a.Ho * a.Wo <= defer_max_px();
+    a.no_finalize = defer ? 1 : 0;
     if (rs) {
       static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
       rs->ptr = nullptr;
@@ -585,11 +617,13 @@ struct Engine {
     }
     it->second.calls += 1;
     it->second.flops = 2.0 * a.M * a.N * a.K;
-    const bool inred = sdmi_gemm_cfg_inred(it->second.cfg) != 0;     // split-K partials combined inside the launch
-    const int nl = (a.ksplit > 1 && !inred) ? 2 : 1;
+    int ks_eff = 1;
     prof_begin(0, 2.0 * a.M * a.N * a.K);
-    TRY(sdmi_launch_gemm(a, it->second.cfg, st));
+    TRY(sdmi_launch_gemm(a, it->second.cfg, st, &ks_eff));
     prof_end();
+    const bool deferred = defer && ks_eff > 1;
+    if (deferred) { pend = true; pend_args = a; pend_args.ksplit = ks_eff; pend_args.no_finalize = 0; pend_key = a.out; }
+    const int nl = (ks_eff > 1 && !deferred) ? 2 : 1;
     launches += nl;
     if (logging) {
       const int cfg = it->second.cfg;
@@ -597,7 +631,7 @@ struct Engine {
       log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
                  a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.ksplit, 2.0 * a.M * a.N * a.K,
                  2.0 * a.N * a.K, a.out_f32, a.res != nullptr);
-      if (a.ksplit > 1 && !inred) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
+      if (ks_eff > 1 && !deferred) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
     }
     return SDMI_OK;
   }
@@ -635,6 +669,7 @@ struct Engine {
   static constexpr size_t kThrashBytes = (size_t)64 << 20;
   char* thrash = nullptr;
   int tune_gemm(const GemmArgs& a0, Plan* best) {
+    TRY(flush_pending());           // the candidates' split-K launches write the slabs a deferred conv may still own
     if (!thrash && !getenv("SDMI_TUNE_WARM")) TRY(dmalloc(&thrash, kThrashBytes));
     hipEvent_t e0, e1;
     SDMI_CHECK_HIP(hipEventCreate(&e0));
@@ -644,7 +679,6 @@ struct Engine {
       if (!sdmi_gemm_cfg_applicable(a0, cfg)) continue;
       for (int ks : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
         if (!ksplit_ok(a0, cfg, ks)) continue;
-        if (ks == 1 && sdmi_gemm_cfg_inred(cfg)) continue;               // the "...r" twin only differs when K is split
         GemmArgs a = a0;
         a.ksplit = ks;
         float us = 1e30f;
@@ -710,11 +744,24 @@ struct Engine {
     g.B = x.B; g.P = x.H * x.W;
     g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
     g.y = y->h; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
+    // x is the output of a split-K conv that has not been combined yet: combine + normalise in one launch
+    const bool from_slab = pend && !x1 && pend_key == (f32 ? (const void*)x.f : (const void*)x.h) && sdmi_gn_launches(g) == 1 &&
+                           pend_args.M == x.B * g.P && pend_args.N == C;
+    if (from_slab) {
+      pend = false;
+      g.slab = pend_args.slab; g.ksplit = pend_args.ksplit; g.sbias = pend_args.bias;
+      g.sres = pend_args.res; g.sres_f32 = pend_args.res_f32;
+      if (pend_args.out_f32) { g.sout = (float*)pend_args.out; g.sout16 = pend_args.out16; }
+      else if (pend_keep16) g.sout16 = (f16*)pend_args.out;        // fp16-only output somebody else still reads
+    } else {
+      TRY(flush_pending());
+    }
     prof_begin(2, 0.0);
     TRY(sdmi_launch_groupnorm(g, st));
     prof_end();
     launches += sdmi_gn_launches(g);
-    if (sdmi_gn_launches(g) == 1) log_launch("gn_fused C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu);
+    if (from_slab) log_launch("gn_fused_slab C=%d P=%d B=%d silu=%d split=%d", C, g.P, g.B, silu, g.ksplit);
+    else if (sdmi_gn_launches(g) == 1) log_launch("gn_fused C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu);
     else { log_launch("gn_stats C=%d P=%d B=%d", C, g.P, g.B); log_launch("gn_apply C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu); }
     return SDMI_OK;
   }
@@ -745,6 +792,7 @@ struct Engine {
     return SDMI_OK;
   }
   int gn_stats(const Act& x, const Act* x1) {
+    TRY(flush_pending());
     GnArgs g;
     memset(&g, 0, sizeof(g));
     const bool f32 = x.f != nullptr;
@@ -762,6 +810,7 @@ struct Engine {
   }
 
   int layernorm(const Act& x, const NormW& w, Act* y) {
+    TRY(flush_pending());
     TRY(new_act(x.B, x.H, x.W, x.C, false, y));
     LnArgs l;
     memset(&l, 0, sizeof(l));
@@ -778,7 +827,8 @@ struct Engine {
 
   // ---- blocks -------------------------------------------------------------------------------
   // UNET_ResidualBlock (sd/diffusion.py:145-209).  bias1 = conv_feature.bias + linear_time(silu(time))
-  int res_block(const ResW& r, const Act& x, const Act* x1, const float* bias1, Act* y) {
+  // y_to_gn: the caller guarantees that the next launch on y is a single-source GroupNorm (an attention block follows)
+  int res_block(const ResW& r, const Act& x, const Act* x1, const float* bias1, Act* y, bool y_to_gn = false) {
     const int cin = x.C + (x1 ? x1->C : 0);
     if (cin != r.cin) { sdmi_set_error("res_block: cin %d vs %d", cin, r.cin); return SDMI_EINVAL; }
     Act t0, h, t1, sk;
@@ -803,7 +853,8 @@ struct Engine {
         a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
         a.bias = bias1; a.out = h.h; a.ldc = h.C;
       }
-      TRY(gemm(a));
+      pend_keep16 = false;                     // h has one reader: groupnorm_merged
+      TRY(gemm(a, nullptr, /*defer=*/true));
     }
     TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
     GemmArgs a = base_args(h, nullptr, r.conv2, x.H, x.W, 1, 0);
@@ -845,12 +896,14 @@ struct Engine {
       a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
       finish(a);
     }
-    TRY(gemm(a));
+    pend_keep16 = true;
+    TRY(gemm(a, nullptr, /*defer=*/y_to_gn));
     return SDMI_OK;
   }
 
   int attention(const f16* q, int ldq, const f16* k, int ldk, int kbs, const f16* vt, int ldvt, f16* o, int ldo, int B,
                 int d, int Sq, int Skv) {
+    TRY(flush_pending());
     AttnArgs t;
     memset(&t, 0, sizeof(t));
     t.q = q; t.ldq = ldq; t.k = k; t.ldk = ldk; t.k_batch_stride = kbs; t.vt = vt; t.ldvt = ldvt;
@@ -877,6 +930,7 @@ struct Engine {
   // out_proj + residual, then the next Linear with its LayerNorm, as one launch (b2b.hip): C = 320 blocks only
   int b2b(const Act& a1, const ConvW& w1, const Act& r1, const Act* s_out, const FoldW& f2, int K2, int partial, float cscale,
           const Act* r2, const Act& y) {
+    TRY(flush_pending());
     B2bArgs t;
     memset(&t, 0, sizeof(t));
     t.a1 = a1.h; t.lda1 = a1.C; t.w1 = w1.w; t.b1 = w1.bias;
@@ -899,6 +953,7 @@ struct Engine {
   // gn != null: a1 is the RAW stream and the block's GroupNorm (statistics already in gn_partial) is applied inside the kernel
   int b2b_qkv(const Act& a1, const NormW* gn, const ConvW& w1, const Act& s_out, const FoldW& f2, float cscale, const Act& qk,
               f16* vt, int S, int ldt) {
+    TRY(flush_pending());
     B2bArgs t;
     memset(&t, 0, sizeof(t));
     t.a1 = a1.h; t.lda1 = a1.C; t.w1 = w1.w; t.b1 = w1.bias;

@@ -84,10 +84,10 @@ __device__ __forceinline__ int out_row(const GemmArgs& p, int m) {
 
 // Shared epilogue: fp32 tile Cs[BM][BN] in LDS -> global (bias, residual, fp32/fp16 outputs, transposed
 // V^T tail, or split-K slab).  All NT threads of the workgroup call it after a barrier.
-template <int BM, int BN, int NT, bool FINAL = false>      // FINAL: the tile already holds the sum over the K-slices
+template <int BM, int BN, int NT>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, int m0, int n0, int kz, int tid,
                                            const float* s_ln = nullptr, int tn = 0, int tiles_n = 1, int vec_off = 0) {
-  if (p.ksplit > 1 && !FINAL) {
+  if (p.ksplit > 1) {
     float* slab = p.slab + (size_t)kz * p.M * p.N;
     for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
       const int row = idx / (BN / 4), c4 = idx % (BN / 4);
@@ -338,14 +338,17 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   if (p.ln_stat != nullptr && tid < BM) {
     const int m = min(m0 + tid, p.M - 1);
     const f32x2* sp = (const f32x2*)p.ln_stat + (size_t)m * p.ln_ntn;
-    float su = 0.f, sq = 0.f;
-    for (int j = 0; j < p.ln_ntn; ++j) { const f32x2 t = sp[j]; su += t[0]; sq += t[1]; }
-    const float inv = 1.f / (float)p.ln_C;
-    const float mean = su * inv;
-    float var = sq * inv - mean * mean;
-    var = var < 0.f ? 0.f : var;
+    // per-n-tile partial sums are fp32; they are combined and the variance E[x^2] - E[x]^2 is taken in fp64 (as the GroupNorm
+    // reductions of norm.hip): in fp32 the cancellation costs ~(mean/sigma)^2 ulps of the variance on rows with a large mean
+    double su = 0.0, sq = 0.0;
+    for (int j = 0; j < p.ln_ntn; ++j) { const f32x2 t = sp[j]; su += (double)t[0]; sq += (double)t[1]; }
+    const double inv = 1.0 / (double)p.ln_C;
+    const double mean_d = su * inv;
+    double var = sq * inv - mean_d * mean_d;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)mean_d;
     s_ln[2 * tid] = mean;
-    s_ln[2 * tid + 1] = rsqrtf(var + p.ln_eps);
+    s_ln[2 * tid + 1] = rsqrtf((float)var + p.ln_eps);
     if (p.ln_out != nullptr && kz == 0 && tn == 0 && m0 + tid < p.M) {      // for splitk_finalize (partial fold + split-K)
       p.ln_out[2 * (m0 + tid)] = mean;
       p.ln_out[2 * (m0 + tid) + 1] = s_ln[2 * tid + 1];
@@ -1426,460 +1429,6 @@ __global__ __launch_bounds__(C::NT) void conv3_gn_kernel(GemmArgs p, int halo_by
   store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
 }
 
-// =============================================================================================
-// General halo-reuse convolution (conv_halo2_kernel): the 3x3 stride-1 convs of the UNet / VAE (sd/diffusion.py:179,205,435),
-// including everything conv3_halo_kernel leaves to the generic path:
-//   * the ResBlock's 1x1 skip conv as extra K chunks (K = 9 Cin + X: sd/diffusion.py:143,209) -- an extra chunk is 64
-//     channels of the raw block input read at the output pixel (centre tap of a halo that is staged the same way);
-//   * the phase-decomposed x2-upsample conv (GemmArgs::phase2): per output parity four taps of the same 3x3 halo;
-//   * tiles that span several whole images (8x8 maps: BM = 128 rows = 2 images), so the weight-streaming M = 128 layers
-//     stage 2.8 KB instead of 16 KB of activations per K-step;
-//   * split-K in whole channel chunks with the partial tiles combined inside the launch (GemmArgs::inred).
-// MFMA shape: v_mfma_f32_16x16x32_f16 -- 80-wide wave tiles (N = 320 / 640 / 1280 are multiples of 160, not of 128) and
-// 0.45 ds_read_b128 per MFMA on a 64x80 wave tile instead of 1.2 on the 32x160 tile of the 32x32x16 form.
-// Roles: WM*WN MFMA waves, NP LDS-DMA waves; one s_barrier per tap interval closes both the RAW window (the DMA waves pass it
-// only after the next interval's weight tile -- and, at a chunk's last interval, the next chunk's halo -- have landed:
-// counted vmcnt) and the WAR window (the MFMA waves pass it after their last LDS read of the interval).
-struct HaloGeo {
-  int halo_bytes;   // one halo buffer: TI*HR*W2 pixels x 128 B, rounded up to 1 KiB
-  int TI, TH;       // images per tile, image rows per image block
-  int HR, W2;       // halo rows per image block (TH + 2), halo row pitch in pixels (W + 2)
-  int rowp, NHI;    // 8-pixel pieces per halo row, pieces per halo
-  int NCm, NX;      // main chunks (Cin / 64), extra (skip) chunks
-  int T;            // taps per main chunk: 9, or 4 (phase2)
-  int tail_off;     // byte offset of the TAIL region: max(2 halos + weight ring, epilogue tile)
-};
-
-template <int BM_, int BN_, int WM_, int WN_, int NP_, int NS_>
-struct KCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NP = NP_, NS = NS_;
-  static constexpr int NWC = WM * WN, NT = 64 * (NWC + NP);
-  static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  static constexpr int B_BYTES = BN * 128, NB = BN / 8, RB = NB / NP;
-  static constexpr int MAXP = 10;               // halo pieces per DMA wave per chunk (launcher checks the shape)
-  static constexpr int TAIL = 2048;             // ticket broadcast word + DMA dump beyond the ring / the epilogue tile
-  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
-  static_assert(NB % NP == 0, "weight staging must divide evenly over the DMA waves");
-  static_assert(NS >= 3 && NS <= 6, "ring depth");
-};
-
-__device__ __forceinline__ void wait_vmcnt_dyn24(int n) {
-  switch (n < 24 ? n : 24) {
-    case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
-    case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-    case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
-    case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-    case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
-    case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break; case 17: wait_vmcnt<17>(); break;
-    case 18: wait_vmcnt<18>(); break; case 19: wait_vmcnt<19>(); break; case 20: wait_vmcnt<20>(); break;
-    case 21: wait_vmcnt<21>(); break; case 22: wait_vmcnt<22>(); break; case 23: wait_vmcnt<23>(); break;
-    default: wait_vmcnt<24>(); break;
-  }
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <class C>
-__global__ __launch_bounds__(C::NT) void conv_halo2_kernel(GemmArgs p, HaloGeo g) {
-  constexpr int BM = C::BM, BN = C::BN, NWC = C::NWC, NP = C::NP, NT = C::NT, NS = C::NS;
-  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, MAXP = C::MAXP;
-#ifdef SDMI_CLK_PROBE
-  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long clk_setup = 0, clk_loop = 0, clk_cs = 0;
-#endif
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave_id >= NWC;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles = tiles_n * (p.M / BM);
-  int kz, tile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    kz = L / tiles;
-    tile = L - kz * tiles;
-  }
-  const int tiles_m = tiles / tiles_n;
-  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
-  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  int Cin = p.C0 + p.C1;
-  int NCm = g.NCm, T = g.T;
-  int c_begin = __builtin_amdgcn_readfirstlane((int)p.csplit[kz]), c_end = __builtin_amdgcn_readfirstlane((int)p.csplit[kz + 1]);
-  int W2 = g.W2, HR = g.HR, TH = g.TH, rowp = g.rowp, NHI = g.NHI, hbytes = g.halo_bytes;
-  PIN_S(Cin); PIN_S(NCm); PIN_S(T); PIN_S(c_begin); PIN_S(c_end); PIN_S(W2); PIN_S(HR); PIN_S(TH); PIN_S(rowp); PIN_S(NHI);
-  PIN_S(hbytes);
-  const int W = p.Wo, Hh = p.Ho;
-  const int rows_img = Hh * W;
-  // phase2: rows are (phase, source pixel); a tile lies inside one phase
-  const int rows_ph = p.phase2 ? (p.M >> 2) : p.M;
-  const int ph = p.phase2 ? m0 / rows_ph : 0;
-  const int mloc = m0 - ph * rows_ph;
-  const int img0 = mloc / rows_img;
-  const int y0 = g.TI == 1 ? (mloc - img0 * rows_img) / W : 0;
-  const f16* w_img = p.w + (size_t)ph * p.w_img_stride;
-  const int py = ph >> 1, px = ph & 1;
-  auto ntap = [&](int c) { return c < NCm ? T : 1; };
-  int nk = 0;
-  for (int c = c_begin; c < c_end; ++c) nk += ntap(c);
-
-  char* const hbase = smem;
-  char* const bring = smem + 2 * hbytes;
-  auto hbuf = [&](int c) { return hbase + ((c - c_begin) & 1) * hbytes; };
-
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (producer) {
-    // ================================ LDS-DMA waves ================================
-    const int pw = wave_id - NWC;
-    const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
-    int h_pix[MAXP], h_gch[MAXP], h_lds[MAXP];
-    unsigned in_mask = 0;                    // per lane: bit j = this lane's pixel of piece j lies inside the image
-    unsigned have_mask = 0, edge_mask = 0;   // wave-uniform: piece j exists / lies in halo row 0 or TH+1 of its image block
-    int npw = 0;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int q = j * NP + pw;
-      const int himg = q / (HR * rowp), rq = q - himg * HR * rowp;
-      const int hy = rq / rowp, seg = rq - hy * rowp;
-      const int hx = 1 + seg * 8 + (lane >> 3);
-      const int hp = (himg * HR + hy) * W2 + hx;
-      const int y = y0 - 1 + hy, x = hx - 1;
-      if (q < NHI) { have_mask |= 1u << j; ++npw; }
-      if (hy == 0 || hy == TH + 1) edge_mask |= 1u << j;
-      if (q < NHI && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi) in_mask |= 1u << j;
-      h_pix[j] = (img0 + himg) * p.Hs * p.Ws + (y >> p.ups) * p.Ws + (x >> p.ups);
-      h_gch[j] = ((lane & 7) ^ ((hp >> 1) & 7)) * 8;
-      h_lds[j] = ((himg * HR + hy) * W2 + 1 + seg * 8) * 128;
-    }
-    const f16* zero = p.zero;
-    const f16* sbase = zero;
-    int sld = 0;
-    unsigned smask = 0;
-    auto open_source = [&](int c) {
-      const bool extra = c >= NCm;
-      const int cabs = (extra ? c - NCm : c) << 6;
-      const int Ca = extra ? p.X0 : p.C0;
-      const bool second = cabs >= Ca;
-      const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
-      sld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
-      sbase = base + (second ? cabs - Ca : cabs);
-      smask = extra ? (have_mask & ~edge_mask) : have_mask;      // the skip segment reads the centre tap only
-    };
-    auto halo_piece = [&](int j, char* hb) -> int {
-      if (!((smask >> j) & 1)) return 0;
-      const f16* gp = ((in_mask >> j) & 1) ? sbase + ((size_t)h_pix[j] * sld + h_gch[j]) : zero + h_gch[j];
-      glds16(gp, hb + h_lds[j]);
-      return 1;
-    };
-    const f16* b_base[RB];
-    bool b_ok[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int q = (i * NP + pw) * 64 + lane;
-      const int row = q >> 3, pc = q & 7;
-      const int gch = (pc ^ ((row >> 1) & 7)) * 8;
-      const int n = n0 + row;
-      b_ok[i] = n < p.N;
-      b_base[i] = b_ok[i] ? w_img + (size_t)n * p.ldw + gch : zero;
-    }
-    int sc = c_begin, stap = 0;              // (chunk, tap) of the next weight tile to stage
-    auto stage_b = [&](int slot) {
-      const int koff = sc < NCm ? stap * Cin + (sc << 6) : T * Cin + ((sc - NCm) << 6);
-      char* sb = bring + slot * C::B_BYTES;
-#pragma unroll
-      for (int i = 0; i < RB; ++i) glds16(b_ok[i] ? b_base[i] + koff : zero, sb + (i * NP + pw) * 1024);
-      if (++stap == ntap(sc)) { stap = 0; ++sc; }
-    };
-    // prologue: halo of the first chunk + the first NS-1 weight tiles
-    open_source(c_begin);
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) (void)halo_piece(j, hbuf(c_begin));
-#pragma unroll
-    for (int s2 = 0; s2 < NS - 1; ++s2)
-      if (s2 < nk) stage_b(s2);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                            // A
-    int nxt = NS - 1, t = 0;
-#ifdef SDMI_CLK_PROBE_FINE
-    unsigned long long pr_issue = 0, pr_vm = 0, pr_bar = 0;
-#endif
-    int n1 = 0, n2 = 0, n3 = 0;                              // DMA instructions issued in the previous intervals
-    int after_halo = 0;                                      // ... issued since the last halo piece
-    for (int c = c_begin; c < c_end; ++c) {
-      const int nt = ntap(c);
-      const bool next = c + 1 < c_end;
-      char* const hbn = hbuf(c + 1);
-      if (next) open_source(c + 1);
-      // pieces of halo(c+1) per interval: all of them at once behind a one-tap chunk, else spread over the first taps so
-      // that none is issued in the chunk's last NS-2 intervals (the counted wait would have to drain the ring for it)
-      const int span = nt - (NS - 2) > 1 ? nt - (NS - 2) : 1;
-      const int ppi = (npw + span - 1) / span;
-      int jn = 0;
-      for (int tau = 0; tau < nt; ++tau, ++t) {
-        int n_iss = 0;
-#ifdef SDMI_CLK_PROBE_FINE
-        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-#endif
-        if (next && jn < MAXP) {
-          int nh = 0;
-#pragma unroll
-          for (int j = 0; j < MAXP; ++j)
-            if (j >= jn && j < jn + ppi) nh += halo_piece(j, hbn);
-          jn += ppi;
-          if (nh) { n_iss += nh; after_halo = 0; }
-        }
-        if (t + NS - 1 < nk) { stage_b(nxt); n_iss += RB; after_halo += RB; }
-        int allowed = n_iss;
-        if (NS >= 4) allowed += n1;
-        if (NS >= 5) allowed += n2;
-        if (NS >= 6) allowed += n3;
-        if (tau == nt - 1 && next && after_halo < allowed) allowed = after_halo;
-#ifdef SDMI_CLK_PROBE_FINE
-        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-#endif
-        wait_vmcnt_dyn24(allowed);
-#ifdef SDMI_CLK_PROBE_FINE
-        const unsigned long long s2 = __builtin_amdgcn_s_memtime();
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef SDMI_CLK_PROBE_FINE
-        pr_issue += s1 - s0; pr_vm += s2 - s1; pr_bar += __builtin_amdgcn_s_memtime() - s2;
-#endif
-        n3 = n2; n2 = n1; n1 = n_iss;
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      }
-    }
-#ifdef SDMI_CLK_PROBE_FINE
-    if (lane == 0 && pw == 0 && blockIdx.x < 512) {
-      g_clk_probe[512 + blockIdx.x][0] = pr_issue; g_clk_probe[512 + blockIdx.x][1] = pr_vm;
-      g_clk_probe[1024 + blockIdx.x][0] = pr_bar;
-    }
-#endif
-  } else {
-    // ================================ MFMA waves ================================
-    const int wm = wave_id / C::WN, wn = wave_id % C::WN;
-    // zero the two padding columns of every halo row, both buffers, once
-    for (int i = tid; i < g.TI * HR * 2 * 8 * 2; i += NWC * 64) {        // (halo row, side, 16-B chunk, buffer)
-      const int buf = i & 1, ch = (i >> 1) & 7, side = (i >> 4) & 1, hrow = i >> 5;
-      const int hp = hrow * W2 + (side ? W + 1 : 0);
-      f16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
-      *(f16x8*)(hbase + buf * hbytes + hp * 128 + ch * 16) = z;
-    }
-    const int r16 = lane & 15, q4 = lane >> 4;
-    int base_hp[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int rr = wm * C::TM + i * 16 + r16;
-      const int himg = g.TI == 1 ? 0 : rr / rows_img;
-      const int rem = rr - himg * rows_img;
-      const int ty = rem / W, tx = rem - ty * W;
-      base_hp[i] = (himg * HR + ty) * W2 + tx;
-    }
-    // byte offset of this lane's k-half-0 fragment of n-block 0 in a weight tile; block j lies 16 rows = 2048 B further and
-    // has the same swizzle key (((row + 16 j) >> 1) & 7 == (row >> 1) & 7): an immediate offset of the ds_read
-    const int b_row0 = wn * C::TN + r16;
-    const int b_rel0 = b_row0 * 128 + ((q4 ^ ((b_row0 >> 1) & 7)) << 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                            // A
-#ifdef SDMI_CLK_PROBE
-    if (tid == 0) clk_setup = __builtin_amdgcn_s_memtime() - clk_t0;
-#endif
-    // Software pipeline over the tap intervals.  The k-half-0 fragments of interval t+1 are requested right after the
-    // barrier of interval t (which the DMA waves pass only once that interval's weight tile / halo has landed) and the
-    // k-half-1 fragments at the top of interval t+1, so every ds_read has a 16-MFMA block to land under; the barrier
-    // itself sits BETWEEN the two MFMA blocks, behind the last LDS read of the interval: the DMA waves get the ring slot back
-    // half an interval before the matrix work on it is finished.
-    //   interval t:  reads h1(t) | MFMA h0(t) | lgkmcnt(0), s_barrier | reads h0(t+1) | MFMA h1(t)
-    // k-half 1 lives 64 B further inside a 128-B row: chunk (4 + q) ^ key = ((q ^ key) ^ 4), i.e. offset ^ 64.
-    int a_rel[FM];
-    const char* hbp = hbase;
-    const char* Bsp = bring;
-    auto frag_addr = [&](int c, int tau, int slot) {
-      int kh, kw;
-      if (c >= NCm) { kh = 1; kw = 1; }
-      else if (T == 9) { kh = tau / 3; kw = tau - kh * 3; }
-      else { kh = py + (tau >> 1); kw = px + (tau & 1); }
-      const int toff = kh * W2 + kw;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int hp = base_hp[i] + toff;
-        a_rel[i] = hp * 128 + ((q4 ^ ((hp >> 1) & 7)) << 4);
-      }
-      hbp = hbuf(c);
-      Bsp = bring + slot * C::B_BYTES;
-    };
-    f16x8 af[2][FM], bf[2][FN];
-    auto read_half = [&](int hsel) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[hsel][i] = *(const f16x8*)(hbp + (hsel ? (a_rel[i] ^ 64) : a_rel[i]));
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[hsel][j] = *(const f16x8*)(Bsp + (hsel ? (b_rel0 ^ 64) : b_rel0) + j * 2048);
-    };
-    auto mfma_half = [&](int hsel) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[hsel][i], bf[hsel][j], acc[i][j], 0, 0, 0);
-    };
-#ifdef SDMI_CLK_PROBE_FINE
-    unsigned long long cs_bar = 0;
-#endif
-    int cur = 0, nc = c_begin, ntau = 0;                     // (chunk, tap) of the interval whose fragments are requested next
-    frag_addr(nc, ntau, cur);
-    read_half(0);
-    for (int t = 0; t < nk; ++t) {
-      read_half(1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_half(0);
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef SDMI_CLK_PROBE_FINE
-      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-#endif
-      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone, as a builtin: hipcc's own wait model then knows the k-half-1
-                                               // fragments have landed (after an asm wait it re-waits for them behind the barrier,
-                                               // which also drains the next interval's reads issued in between)
-      __builtin_amdgcn_s_barrier();
-#ifdef SDMI_CLK_PROBE_FINE
-      cs_bar += __builtin_amdgcn_s_memtime() - s0;
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) {
-        if (++ntau == ntap(nc)) { ntau = 0; ++nc; }
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        frag_addr(nc, ntau, cur);
-        read_half(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_half(1);
-    }
-#ifdef SDMI_CLK_PROBE_FINE
-    if (lane == 0 && wave_id == 0 && blockIdx.x < 512) {
-      g_clk_probe[1536 + blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk_t0 - cs_bar; g_clk_probe[1536 + blockIdx.x][1] = cs_bar;
-    }
-#endif
-  }
-
-#ifdef SDMI_CLK_PROBE
-  clk_loop = __builtin_amdgcn_s_memtime() - clk_t0;
-#endif
-  // ---- epilogue: accumulators -> LDS (fp32 [BM][BN]) -> (split-K combine) -> global ----------------------------------
-  float* Cs = (float*)smem;
-  if (!producer) {
-    const int wm = wave_id / C::WN, wn = wave_id % C::WN;
-    const int r16 = lane & 15, q4 = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = wm * C::TM + i * 16 + q4 * 4 + e;
-          const int col = wn * C::TN + j * 16 + r16;
-          Cs[row * BN + col] = acc[i][j][e];
-        }
-  }
-  __syncthreads();
-#ifdef SDMI_CLK_PROBE
-  clk_cs = __builtin_amdgcn_s_memtime() - clk_t0;
-#define SDMI_PHASE_END()                                                                                                  \
-  do {                                                                                                                    \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
-    if (tid == 0 && blockIdx.x < 2048) {                                                                                  \
-      g_clk_phase[blockIdx.x][0] = clk_r0; g_clk_phase[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                \
-      g_clk_phase[blockIdx.x][2] = clk_setup; g_clk_phase[blockIdx.x][3] = clk_loop; g_clk_phase[blockIdx.x][4] = clk_cs;  \
-      g_clk_phase[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - clk_t0;                                                 \
-    }                                                                                                                     \
-  } while (0)
-#else
-#define SDMI_PHASE_END() do {} while (0)
-#endif
-  if (p.ksplit > 1 && p.inred) {
-    int* s_flag = (int*)(smem + g.tail_off);                     // behind the ring and the epilogue tile
-    int* cnt = p.tile_cnt + 2 * tile;
-    if (tid == 0) s_flag[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int ticket = s_flag[0];
-    const size_t MN = (size_t)p.M * p.N;
-    // descriptor from provably wave-uniform words (a VGPR-held descriptor makes hipcc wrap every buffer op in a waterfall loop)
-    const unsigned long long sl = (unsigned long long)p.slab;
-    const unsigned sl_lo = __builtin_amdgcn_readfirstlane((unsigned)sl), sl_hi = __builtin_amdgcn_readfirstlane((unsigned)(sl >> 32));
-    const int sl_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)p.ksplit * MN * 4));                  // < 2 GiB (launcher)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)sl_hi << 32) | sl_lo), 0, sl_bytes, 0x00020000);
-    if (ticket < p.ksplit - 1) {
-      // not the last slice of this tile: publish the partial tile write-through (no release fence needed), drain, count
-      for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
-        const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-        const int m = m0 + row, n = n0 + c4 * 4;
-        if (m < p.M && n < p.N) {
-          const u32x4 v = *(const u32x4*)(Cs + row * BN + c4 * 4);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((size_t)kz * MN + (size_t)m * p.N + n) * 4), 0, 16 /* sc1 */);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) (void)__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      SDMI_PHASE_END();
-      return;
-    }
-    // last slice: wait until the other ksplit-1 tiles are in memory, then add them in slab order
-    if (tid == 0) {
-      int spins = 0;
-      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.ksplit - 1 && spins < (1 << 22)) {
-        __builtin_amdgcn_s_sleep(4);
-        ++spins;
-      }
-      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counters are zero between launches
-      __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
-      const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
-      const int m = m0 + row, n = n0 + c4 * 4;
-      if (m < p.M && n < p.N) {
-        f32x4 own = *(const f32x4*)(Cs + row * BN + c4 * 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int off = (int)(((size_t)m * p.N + n) * 4);
-        for (int z0 = 0; z0 < p.ksplit; z0 += 4) {
-          u32x4 s[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (z0 + j < p.ksplit && z0 + j != kz) s[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + (int)((size_t)(z0 + j) * MN * 4), 0, 16 /* sc1 */);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (z0 + j < p.ksplit) {
-              if (z0 + j == kz) { v += own; }
-              else {
-                v += __builtin_bit_cast(f32x4, s[j]);      // (bit_cast of single elements, s[j][e], is folded to element 0 by hipcc 7.2)
-              }
-            }
-        }
-        *(f32x4*)(Cs + row * BN + c4 * 4) = v;
-      }
-    }
-    __syncthreads();
-    store_tile<BM, BN, NT, true>(p, Cs, m0, n0, kz, tid);
-    SDMI_PHASE_END();
-    return;
-  }
-  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
-  SDMI_PHASE_END();
-}
-
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
@@ -1982,8 +1531,6 @@ struct CfgInfo {
   void (*kern)(GemmArgs);
   void (*hkern)(GemmArgs, int);   // halo-reuse 3x3 kernel (kern == nullptr)
   int ntaph, nw;
-  void (*h2kern)(GemmArgs, HaloGeo) = nullptr;   // general halo kernel (conv_halo2_kernel): nw = DMA waves, ntaph = pieces per DMA wave
-  int inred = 0;                                 // split-K partials combined inside the launch
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
@@ -2053,33 +1600,17 @@ const CfgInfo kGnCfgs[] = {
 };
 constexpr int kNumGn = sizeof(kGnCfgs) / sizeof(kGnCfgs[0]);
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-// general halo kernel: "k<BM>x<BN>s<NS>" (split-K through slabs + splitk_finalize) and "...r" (combined inside the launch)
-#define CFG_ENTRY_K(BM, BN, WM, WN, NP, NS, TAG) \
-  {"k" #BM "x" #BN "s" #NS TAG, BM, BN, NS, KCfg<BM, BN, WM, WN, NP, NS>::NT, 0, nullptr, nullptr, KCfg<BM, BN, WM, WN, NP, NS>::MAXP, NP, \
-   conv_halo2_kernel<KCfg<BM, BN, WM, WN, NP, NS>>, 0},                                                                              \
-  {"k" #BM "x" #BN "s" #NS TAG "r", BM, BN, NS, KCfg<BM, BN, WM, WN, NP, NS>::NT, 0, nullptr, nullptr, KCfg<BM, BN, WM, WN, NP, NS>::MAXP, NP, \
-   conv_halo2_kernel<KCfg<BM, BN, WM, WN, NP, NS>>, 1}
-const CfgInfo kH2Cfgs[] = {
-    CFG_ENTRY_K(128, 160, 2, 2, 4, 3, ""), CFG_ENTRY_K(128, 160, 2, 2, 5, 3, "p5"), CFG_ENTRY_K(128, 160, 4, 2, 5, 3, "w8p5"),
-    CFG_ENTRY_K(128, 128, 2, 2, 4, 3, ""), CFG_ENTRY_K(128, 128, 2, 2, 8, 3, "p8"),
-    CFG_ENTRY_K(256, 128, 4, 2, 4, 3, ""), CFG_ENTRY_K(128, 64, 2, 2, 4, 4, ""),  CFG_ENTRY_K(128, 64, 2, 2, 8, 4, "p8"),
-};
-constexpr int kNumH2 = sizeof(kH2Cfgs) / sizeof(kH2Cfgs[0]);
 constexpr int kMaxDev = 16;
-bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo + kNumGn + kNumH2] = {};   // hipFuncSetAttribute is per device
-int* g_tile_cnt[kMaxDev] = {};                                            // in-launch split-K tickets (GemmArgs::tile_cnt)
-constexpr int kMaxTiles = 4096;
+bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo + kNumGn] = {};   // hipFuncSetAttribute is per device
 
 }  // namespace
 
 static const CfgInfo& cfg_info(int cfg) {
   if (cfg < kNumCfgs) return kCfgs[cfg];
   if (cfg < kNumCfgs + kNumHalo) return kHaloCfgs[cfg - kNumCfgs];
-  if (cfg < kNumCfgs + kNumHalo + kNumGn) return kGnCfgs[cfg - kNumCfgs - kNumHalo];
-  return kH2Cfgs[cfg - kNumCfgs - kNumHalo - kNumGn];
+  return kGnCfgs[cfg - kNumCfgs - kNumHalo];
 }
-int sdmi_gemm_num_cfgs() { return kNumCfgs + kNumHalo + kNumGn + kNumH2; }
-int sdmi_gemm_cfg_inred(int cfg) { return cfg >= 0 && cfg < sdmi_gemm_num_cfgs() ? cfg_info(cfg).inred : 0; }
+int sdmi_gemm_num_cfgs() { return kNumCfgs + kNumHalo + kNumGn; }
 const char* sdmi_gemm_cfg_name(int cfg) {
   if (cfg >= 0 && cfg < sdmi_gemm_num_cfgs()) return cfg_info(cfg).name;
   return "?";
@@ -2124,41 +1655,9 @@ static bool gn_ok(const GemmArgs& a, const CfgInfo& c) {
   return true;
 }
 
-// conv_halo2_kernel: geometry of a launch, or false when the config does not apply.  3x3 stride-1 pad-1 convs (optionally
-// x2-upsampled input, two concat sources, fused 1x1 skip segment) and the phase-decomposed upsample conv; a tile is whole
-// image rows inside one image, or several whole images.
-static bool halo2_geo(const GemmArgs& a, const CfgInfo& c, HaloGeo* g) {
-  const bool ph = a.phase2 != 0;
-  if (!ph && !(a.ks == 3 && a.stride == 1 && a.pad == 1)) return false;
-  if (a.rowstat || a.ln_stat || a.outT || a.act || a.gn_partial) return false;
-  if (!ph && a.img_rows) return false;
-  if (!ph && ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo)) return false;
-  if (ph && (a.Hs != a.Ho || a.Ws != a.Wo)) return false;
-  const int W = a.Wo, H = a.Ho;
-  if (W < 8 || W % 8 != 0) return false;
-  const int rows_img = H * W, Mloc = ph ? a.M / 4 : a.M;
-  if (Mloc % c.BM != 0 || Mloc % rows_img != 0) return false;
-  if (c.BM <= rows_img) {
-    if (c.BM % W != 0 || rows_img % c.BM != 0) return false;
-    g->TI = 1; g->TH = c.BM / W;
-  } else {
-    if (c.BM % rows_img != 0) return false;
-    g->TI = c.BM / rows_img; g->TH = H;
-  }
-  g->HR = g->TH + 2; g->W2 = W + 2; g->rowp = W / 8; g->NHI = g->TI * g->HR * g->rowp;
-  if (g->NHI > c.ntaph /* = MAXP */ * c.nw /* = NP */) return false;
-  g->halo_bytes = ((g->TI * g->HR * g->W2 * 128) + 1023) / 1024 * 1024;
-  g->NCm = (a.C0 + a.C1) / 64; g->NX = (a.X0 + a.X1) / 64; g->T = ph ? 4 : 9;
-  const int ring = 2 * g->halo_bytes + c.NS * c.BN * 128, cs = c.BM * c.BN * 4;
-  g->tail_off = ring > cs ? ring : cs;
-  if (g->tail_off + 2048 > 160 * 1024) return false;
-  return true;
-}
-
 bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= sdmi_gemm_num_cfgs()) return false;
   const CfgInfo& c = cfg_info(cfg);
-  if (cfg >= kNumCfgs + kNumHalo + kNumGn) { HaloGeo g; return halo2_geo(a, c, &g); }
   if (cfg >= kNumCfgs + kNumHalo) return gn_ok(a, c);
   if (a.gn_partial) return false;               // only the fused kernel normalises the A operand
   if (c.BN % 64 != 0 && (a.ks != 3 || a.rowstat || a.ln_stat || a.outT)) return false;   // 160-wide tiles: 3x3 convs only
@@ -2187,7 +1686,7 @@ size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int /*cfg*/, int ksplit) {
   return ksplit > 1 ? (size_t)ksplit * a.M * a.N * sizeof(float) : 0;
 }
 
-int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
+int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out) {
   SDMI_REQUIRE(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
   SDMI_REQUIRE(a.N % 8 == 0 && a.N > 0, "gemm: N=%d must be a positive multiple of 8", a.N);
   SDMI_REQUIRE(a.M > 0, "gemm: M=%d", a.M);
@@ -2218,12 +1717,9 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     }
   }
   SDMI_REQUIRE(cfg < sdmi_gemm_num_cfgs(), "gemm: bad cfg %d", cfg);
-  const bool h2 = cfg >= kNumCfgs + kNumHalo + kNumGn;
-  const bool gnk = cfg >= kNumCfgs + kNumHalo && !h2;
-  const bool halo = cfg >= kNumCfgs && !gnk && !h2;
+  const bool gnk = cfg >= kNumCfgs + kNumHalo;
+  const bool halo = cfg >= kNumCfgs && !gnk;
   const CfgInfo& c = cfg_info(cfg);
-  HaloGeo geo = {};
-  if (h2) SDMI_REQUIRE(halo2_geo(a, c, &geo), "gemm: halo config %s not applicable to this conv", c.name);
   if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
   SDMI_REQUIRE(c.BN % 64 == 0 || (a.ks == 3 && !a.rowstat && !a.ln_stat && !a.outT), "gemm: config %s (160-wide tile) is not applicable to this GEMM: 3x3 convs only", c.name);
   if (gnk) SDMI_REQUIRE(gn_ok(a, c), "gemm: fused-GroupNorm config %s not applicable to this conv", c.name);
@@ -2231,7 +1727,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && !gnk && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
                               a.sm_valid > 0 && a.sm_valid <= 128),
                "gemm: the softmax epilogue needs a BN=128 plain tile, full tiles (M %% BM == 0, N %% 128 == 0), fp16 output, no split-K / residual");
-  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && (a.ks == 1 || a.phase2) && (a.ksplit <= 1 || a.phase2) && (!h2 || a.phase2)),
+  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && (a.ks == 1 || a.phase2) && (a.ksplit <= 1 || a.phase2)),
                "gemm: per-image weights need BM | img_rows | M, a 1x1 GEMM and no split-K");
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
@@ -2262,20 +1758,6 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     p.ksteps_per = (NC + ks - 1) / ks;
     p.ksplit = (NC + p.ksteps_per - 1) / p.ksteps_per;
   }
-  if (h2) {                                             // whole channel chunks per K-slice, balanced by K-steps
-    const int NC = geo.NCm + geo.NX, total = geo.NCm * geo.T + geo.NX;
-    int ks = a.ksplit < 1 ? 1 : (a.ksplit > NC ? NC : a.ksplit);
-    if (ks > 16) ks = 16;
-    auto cum = [&](int c2) { return (c2 < geo.NCm ? c2 : geo.NCm) * geo.T + (c2 > geo.NCm ? c2 - geo.NCm : 0); };
-    p.csplit[0] = 0;
-    int z = 1;
-    for (int c2 = 1; c2 < NC && z < ks; ++c2)
-      if ((long)cum(c2) * ks >= (long)z * total && NC - c2 >= ks - z) p.csplit[z++] = (short)c2;
-    p.ksplit = z;
-    p.csplit[z] = (short)NC;
-    p.ksteps_per = (total + z - 1) / z;
-    p.inred = c.inred && p.ksplit > 1;
-  }
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
   const int tiles = ((a.M + c.BM - 1) / c.BM) * ((a.N + c.BN - 1) / c.BN);
   int dev = 0;
@@ -2289,20 +1771,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     }
     return SDMI_OK;
   };
-  if (h2) {
-    SDMI_REQUIRE((size_t)p.ksplit * a.M * a.N * 4 < ((size_t)1 << 31), "gemm: split-K slabs of %d x %d x %d exceed 2 GiB", p.ksplit, a.M, a.N);
-    if (p.inred) {
-      SDMI_REQUIRE(tiles <= kMaxTiles, "gemm: %d tiles exceed the in-launch split-K ticket table", tiles);
-      if (!g_tile_cnt[dev]) {
-        SDMI_CHECK_HIP(hipMalloc((void**)&g_tile_cnt[dev], (size_t)kMaxTiles * 2 * sizeof(int)));
-        SDMI_CHECK_HIP(hipMemset(g_tile_cnt[dev], 0, (size_t)kMaxTiles * 2 * sizeof(int)));
-      }
-      p.tile_cnt = g_tile_cnt[dev];
-    }
-    if (set_attr((const void*)c.h2kern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
-    hipLaunchKernelGGL(c.h2kern, dim3(tiles * p.ksplit), dim3(c.NT), geo.tail_off + 2048, st, p, geo);
-    SDMI_CHECK_HIP(hipGetLastError());
-  } else if (gnk) {
+  if (gnk) {
     if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
     hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), gn_lds_bytes(a, c), st, p, gn_halo_bytes(a, c));
     SDMI_CHECK_HIP(hipGetLastError());
@@ -2320,7 +1789,8 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     hipLaunchKernelGGL(c.kern, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
     SDMI_CHECK_HIP(hipGetLastError());
   }
-  if (p.ksplit > 1 && !p.inred) {
+  if (ksplit_out) *ksplit_out = p.ksplit;
+  if (p.ksplit > 1 && !p.no_finalize) {
     const size_t total8 = (size_t)p.M * (p.N / 8);
     int blocks = (int)((total8 + 255) / 256);
     if (blocks > 2048) blocks = 2048;

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
 // Accesses are 4 channels wide (16-B fp32 / 8-B fp16 loads, 8-B stores): the first form moved 2 channels per access
 // (4-byte stores) and spent most of its 6-11 us issuing them.
 constexpr int GNF_NT = 512;
-template <int MAXQ>
+// SLAB: the slab of the (group, image) is not read from a tensor but summed from the split-K partial sums of the producing
+// conv (GnArgs::slab), + bias (+ residual), in slab order like splitk_finalize: that launch and its 0.5 - 1 GB/step of
+// round trip through the finished tensor are gone, and the statistics are taken from the fp32 sums instead of their fp16 copy.
+template <int MAXQ, bool SLAB>
 __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   __shared__ float s_w[2][GNF_NT / 64];
   const int C = p.C0 + p.C1, cpg = C / 32, q4 = cpg / 4;
@@ -184,22 +187,73 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   const int px_first = tid / q4, j_first = tid - px_first * q4;
   const int dpx = GNF_NT / q4, dj = GNF_NT - dpx * q4;
   int px = px_first, j = j_first;
+  if constexpr (SLAB) {
+    // 64 workgroups pull ksplit x (their share of the map): what matters is bytes in flight.  Slab-major order -- for each
+    // slab (or group of ZB slabs) the loads of ALL of this thread's slots are issued before anything is added -- keeps
+    // MAXQ (x ZB) 16-byte loads per thread outstanding instead of one slot's four; the additions per element stay in slab
+    // order, so the sum is bit-identical to splitk_finalize's.
+    const size_t MN = (size_t)p.B * p.P * C;
+    constexpr int ZB = MAXQ <= 4 ? 4 : 1;
+    size_t off[MAXQ];
+    bool ok[MAXQ];
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i) {
-    const int slot = tid + i * GNF_NT;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (slot < total) {
-      const int c = g * cpg + 4 * j;
-      const bool second = c >= p.C0;
-      const void* base = second ? p.x1 : p.x0;
-      const int cs = second ? p.C1 : p.C0;
-      const size_t off = ((size_t)n * p.P + px) * cs + (second ? c - p.C0 : c);
-      if (p.in_f32) v[i] = *(const f32x4*)((const float*)base + off);
-      else { const f16x4 hv = *(const f16x4*)((const f16*)base + off); v[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
+    for (int i = 0; i < MAXQ; ++i) {
+      ok[i] = tid + i * GNF_NT < total;
+      off[i] = ok[i] ? ((size_t)n * p.P + px) * C + g * cpg + 4 * j : 0;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      px += dpx; j += dj;
+      if (j >= q4) { j -= q4; ++px; }
     }
-    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    px += dpx; j += dj;
-    if (j >= q4) { j -= q4; ++px; }
+    f32x4 r[MAXQ];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {                 // residual first: the coldest load
+      r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[i] && p.sres) {
+        if (p.sres_f32) r[i] = *(const f32x4*)((const float*)p.sres + off[i]);
+        else { const f16x4 hv = *(const f16x4*)((const f16*)p.sres + off[i]); r[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
+      }
+    }
+    for (int z0 = 0; z0 < p.ksplit; z0 += ZB) {
+      f32x4 t[ZB][MAXQ];
+#pragma unroll
+      for (int zz = 0; zz < ZB; ++zz)
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i)
+          t[zz][i] = (ok[i] && z0 + zz < p.ksplit) ? *(const f32x4*)(p.slab + (size_t)(z0 + zz) * MN + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int zz = 0; zz < ZB; ++zz)
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i)
+          if (z0 + zz < p.ksplit) v[i] += t[zz][i];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+      if (ok[i]) {
+        if (p.sbias) v[i] += *(const f32x4*)(p.sbias + (off[i] % C));
+        v[i] += r[i];
+        if (p.sout) *(f32x4*)(p.sout + off[i]) = v[i];
+        if (p.sout16) *(f16x4*)(p.sout16 + off[i]) = f16x4{(f16)v[i][0], (f16)v[i][1], (f16)v[i][2], (f16)v[i][3]};
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+      const int slot = tid + i * GNF_NT;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (slot < total) {
+        const int c = g * cpg + 4 * j;
+        const bool second = c >= p.C0;
+        const void* base = second ? p.x1 : p.x0;
+        const int cs = second ? p.C1 : p.C0;
+        const size_t off = ((size_t)n * p.P + px) * cs + (second ? c - p.C0 : c);
+        if (p.in_f32) v[i] = *(const f32x4*)((const float*)base + off);
+        else { const f16x4 hv = *(const f16x4*)((const f16*)base + off); v[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}; }
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      px += dpx; j += dj;
+      if (j >= q4) { j -= q4; ++px; }
+    }
   }
   auto block_sum = [&](float x, int which) {
 #pragma unroll
@@ -330,14 +384,21 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
   SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "groupnorm: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
   SDMI_REQUIRE(C / 8 <= 320 && C >= 128, "groupnorm: C=%d out of range (128..2560)", C);
-  SDMI_REQUIRE(a.partial && a.y && a.x0 && a.gamma && a.beta, "groupnorm: null pointer");
+  SDMI_REQUIRE(a.partial && a.y && (a.x0 || a.slab) && a.gamma && a.beta, "groupnorm: null pointer");
   SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
+  SDMI_REQUIRE(!a.slab || (a.C1 == 0 && a.ksplit >= 1 && sdmi_gn_launches(a) == 1),
+               "groupnorm: the split-K slab input needs one source and a map the single-launch kernel takes");
   if (sdmi_gn_launches(a) == 1) {
     {
       const long quads = ((long)a.P * (C / 128) + GNF_NT - 1) / GNF_NT;
       const dim3 grid(32, a.B), block(GNF_NT);
-      if (quads <= 4) hipLaunchKernelGGL(gn_fused_kernel<4>, grid, block, 0, st, a);
-      else hipLaunchKernelGGL(gn_fused_kernel<12>, grid, block, 0, st, a);
+      if (a.slab) {
+        if (quads <= 4) hipLaunchKernelGGL((gn_fused_kernel<4, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gn_fused_kernel<12, true>), grid, block, 0, st, a);
+      } else {
+        if (quads <= 4) hipLaunchKernelGGL((gn_fused_kernel<4, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gn_fused_kernel<12, false>), grid, block, 0, st, a);
+      }
       SDMI_CHECK_HIP(hipGetLastError());
       return SDMI_OK;
     }

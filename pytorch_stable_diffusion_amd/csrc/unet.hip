@@ -121,7 +121,9 @@ int run_stage(sdmi_unet* u, const std::string& grp_prefix, const Stage& stage, A
       case 1: {
         auto it = u->res.find(p);
         if (it == u->res.end()) { sdmi_set_error("block '%s' not loaded", p.c_str()); return SDMI_ENOENT; }
-        TRY(u->res_block(it->second, cur, (first ? skip : nullptr), tv + it->second.time_off, &y));
+        // an attention block next: its GroupNorm is the only launch between conv_merged and everything else that reads y
+        const bool to_gn = j + 1 < stage.size() && stage[j + 1].kind == 2;
+        TRY(u->res_block(it->second, cur, (first ? skip : nullptr), tv + it->second.time_off, &y, to_gn));
         break;
       }
       case 2: {
@@ -140,6 +142,7 @@ int run_stage(sdmi_unet* u, const std::string& grp_prefix, const Stage& stage, A
     cur = y;
     first = false;
   }
+  TRY(u->flush_pending());
   *out = cur;
   return SDMI_OK;
 }
@@ -580,6 +583,22 @@ int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1
   memset(&g, 0, sizeof(g));
   g.x0 = x0; g.x1 = x1; g.in_f32 = in_f32; g.C0 = c0; g.C1 = c1; g.B = B; g.P = P; g.gamma = gamma; g.beta = beta;
   g.eps = eps; g.silu = silu; g.y = (f16*)y_f16; g.partial = partial; g.nchunk = sdmi_gn_nchunk(P);
+  return sdmi_launch_groupnorm(g, (hipStream_t)stream);
+}
+
+// GroupNorm(32)(+SiLU) of x = sum_z slab[z] + bias (+ res): the split-K combine of a conv and the norm that follows it in one
+// launch (maps the single-launch kernel takes: P <= 1024, (C/32) % 4 == 0).  out32 / out16: optional copies of x.
+int sdmi_op_groupnorm_slab(const float* slab, int ksplit, const float* bias, const void* res, int res_f32, int C, int B, int P,
+                           const float* gamma, const float* beta, float eps, int silu, void* y_f16, float* out32, void* out16,
+                           void* stream) {
+  static float* partial = nullptr;
+  if (!partial) SDMI_CHECK_HIP(hipMalloc((void**)&partial, (size_t)64 * 128 * 32 * 2 * 4));
+  SDMI_REQUIRE(slab && ksplit >= 1 && B <= 64, "op_groupnorm_slab: bad arguments");
+  GnArgs g;
+  memset(&g, 0, sizeof(g));
+  g.C0 = C; g.B = B; g.P = P; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu; g.y = (f16*)y_f16;
+  g.partial = partial; g.nchunk = sdmi_gn_nchunk(P);
+  g.slab = slab; g.ksplit = ksplit; g.sbias = bias; g.sres = res; g.sres_f32 = res_f32; g.sout = out32; g.sout16 = (f16*)out16;
   return sdmi_launch_groupnorm(g, (hipStream_t)stream);
 }
 

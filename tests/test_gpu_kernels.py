@@ -29,16 +29,9 @@ def test_library_loaded_is_in_tree():
 def _plain_cfgs():
     from pytorch_stable_diffusion_amd import _native as N
     lib = N.load()
-    # "h..." / "k..." (halo-reuse), "g..." (fused GroupNorm) and the 160-wide tiles are 3x3-conv configs with their own tests
+    # "h..." (halo-reuse), "g..." (fused GroupNorm) and the 160-wide tiles are 3x3-conv configs with their own tests
     names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
-    return [i for i, nm in enumerate(names) if nm[0] not in "hgk" and "x160" not in nm]
-
-
-def _k_cfgs():
-    """the general halo kernel (csrc/gemm.hip conv_halo2_kernel): "k<BM>x<BN>s<NS>", "...r" = split-K combined in the launch"""
-    lib = N_.load()
-    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
-    return [i for i, nm in enumerate(names) if nm[0] == "k"]
+    return [i for i, nm in enumerate(names) if nm[0] not in "hg" and "x160" not in nm]
 
 
 @pytest.mark.parametrize("cfg", _plain_cfgs())
@@ -111,10 +104,9 @@ def test_conv_implicit_gemm(case):
     ref = _conv_ref(xin, w, c["stride"], c["ups"])
     Ho, Wo = ref.shape[1], ref.shape[2]
     wp = G.pack_conv(w.to(DEV))
-    n_halo = n_k = 0
-    kset = set(_k_cfgs())
+    n_halo = 0
     for cfg in [-1] + _cfgs():
-        for ksplit in (1, 3, 4) if cfg in kset else (1, 3):
+        for ksplit in (1, 3):
             try:
                 out = G.igemm(x0.to(DEV), wp, B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"],
                               ups=c["ups"], a1=None if x1 is None else x1.to(DEV), out_f32=True, cfg=cfg, ksplit=ksplit)
@@ -122,13 +114,11 @@ def test_conv_implicit_gemm(case):
                 assert "not applicable" in str(exc) or "LDS" in str(exc), exc
                 continue
             n_halo += cfg >= 0 and N_.load().sdmi_gemm_config_name(cfg).decode()[0] == "h"
-            n_k += cfg in kset
             err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
             G.log_metric(test="conv", case=str(c), cfg=cfg, ksplit=ksplit, max_abs_err=err)
             assert err < 2e-3, f"{c} cfg {cfg} ksplit {ksplit}: max abs err {err}"
     if c["ks"] == 3 and c["stride"] == 1 and c["W"] << c["ups"] in (8, 16, 32, 64):
-        assert n_halo > 0 or c["B"] * (c["H"] << c["ups"]) * (c["W"] << c["ups"]) % 128, "no halo-reuse config ran on an eligible conv"
-        assert n_k > 0 or (c["B"] * (c["H"] << c["ups"]) * (c["W"] << c["ups"])) % 128, "the general halo kernel did not run on an eligible conv"
+        assert n_halo > 0, "no halo-reuse config ran on an eligible conv"
 
 
 @pytest.mark.parametrize("X0,X1,H,W", [(64, 0, 16, 16), (128, 64, 12, 12), (192, 128, 8, 8)])
@@ -145,23 +135,19 @@ def test_conv_with_fused_skip_segment(X0, X1, H, W):
     xs = x0 if x1 is None else torch.cat([x0, x1], -1)
     ref = _conv_ref(t, w3, 1, 0) + _conv_ref(xs, ws, 1, 0)
     wp = torch.cat([G.pack_conv(w3.to(DEV)), G.pack_conv(ws.to(DEV))], 1).contiguous()
-    ran = ran_k = 0
-    kset = set(_k_cfgs())
+    ran = 0
     for cfg in [-1] + _cfgs():
         for ksplit in (1, 2, 5):
             try:
                 out = G.igemm(t.to(DEV), wp, B=B, Hs=H, Ws=W, Ho=H, Wo=W, ks=3, out_f32=True, cfg=cfg, ksplit=ksplit,
                               x0=x0.to(DEV), x1=None if x1 is None else x1.to(DEV))
-            except ValueError as exc:       # the first-generation halo kernels do not take the extra segment
+            except ValueError as exc:       # halo-reuse kernels do not take the extra segment
                 assert "not applicable" in str(exc) or "LDS" in str(exc), exc
                 continue
             ran += 1
-            ran_k += cfg in kset
             err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
             assert err < 2e-3, f"cfg {cfg} ksplit {ksplit}: max abs err {err}"
     assert ran >= 3 * len(_plain_cfgs())
-    if W in (8, 16):
-        assert ran_k >= 3, "the general halo kernel did not take the fused skip segment"
 
 
 def test_gemm_transposed_tail():
@@ -215,21 +201,27 @@ def test_flash_attention(d, Sq, Skv):
     assert err < 2e-3, f"d={d} Sq={Sq} Skv={Skv}: max abs err {err}"       # measured 1.4e-4 .. 8.1e-4
 
 
-def test_flash_attention_large_logits():
-    """Online-softmax rescale path: one key dominates late in the sequence (max jumps between tiles)."""
-    B, Hh, d, S = 1, 8, 40, 512
-    g = torch.Generator().manual_seed(3)
+@pytest.mark.parametrize("S,d", [(512, 40), (2048, 40), (4096, 40), (1024, 80), (2048, 160)])
+def test_flash_attention_large_logits(S, d):
+    """Online-softmax rescale path of BOTH kernel forms -- the key-split form (S <= 1024) and the one-chain form that carries
+    the S = 4096 / 9216 self-attention (csrc/attention.hip) -- on data that forces it: single keys dominate their query late in
+    the sequence, so the running max of a 32-query block jumps between 64-key tiles, several times and in its last tile."""
+    B, Hh = 1, 8
+    g = torch.Generator().manual_seed(3 + S)
     q = torch.randn((B * S, Hh * d), generator=g).half()
     k = torch.randn((B * S, Hh * d), generator=g).half()
-    v = torch.randn((B * S, Hh * d), generator=g).half()
-    k[300] = (q[7] * 4).half()         # spike: query 7 . key 300 >> others, in tile 4
-    k[40] = (q[100] * 3).half()
+    v = (0.5 * torch.randn((B * S, Hh * d), generator=g)).half()      # |o| < 2.5: the fp16 output's own half-ulp stays below 1e-3
+    amp = 4.0 * math.sqrt(40.0 / d)                 # keeps the spike's logit ~ 4 |q|^2 / sqrt(d) of the d = 40 case
+    k[300] = (q[7] * amp).half()                    # query 7 . key 300 >> others: tile 4
+    k[40] = (q[100] * 0.75 * amp).half()
+    k[S - 3] = (q[S // 2 + 5] * amp).half()         # a jump in the LAST tile of the sequence
+    k[S // 2 + 70] = (q[7] * 1.5 * amp).half()      # the same query's max jumps a second time, later
     ref = _attn_ref(q, k, v, B, Hh, d, S, S)
     vt = v.view(B, S, Hh * d).permute(0, 2, 1).contiguous().view(B * Hh * d, S)
     out = G.attention(q.to(DEV), k.to(DEV), vt.to(DEV), B, Hh, d, S, S)
     err = (out.cpu().double() - ref).abs().max().item()
-    G.log_metric(test="attention_spike", max_abs_err=err)
-    assert err < 2.5e-3, f"max abs err {err}"
+    G.log_metric(test="attention_spike", S=S, d=d, max_abs_err=err)
+    assert err < 2.5e-3, f"S={S} d={d}: max abs err {err}"
 
 
 @pytest.mark.parametrize("C0,C1,P,in_f32,silu,eps", [(320, 0, 64, True, True, 1e-5), (640, 320, 256, False, True, 1e-5),
@@ -255,6 +247,47 @@ def test_groupnorm(C0, C1, P, in_f32, silu, eps):
     err = (y.cpu().double() - ref).abs().max().item()
     G.log_metric(test="groupnorm", C0=C0, C1=C1, P=P, max_abs_err=err)
     assert err < 4e-3, f"max abs err {err}"        # measured 1.95e-3 = half an fp16 ulp of the largest outputs (|y| ~ 4)
+
+
+@pytest.mark.parametrize("C,P,ksplit,res,silu", [(1280, 64, 12, None, 1), (1280, 256, 6, "f32", 1), (640, 1024, 3, "f16", 0),
+                                                 (640, 256, 5, "f32", 1), (2560, 64, 16, None, 1)])
+def test_groupnorm_from_split_k_slabs(C, P, ksplit, res, silu):
+    """The split-K combine of a conv and the GroupNorm behind it in one launch (csrc/norm.hip gn_fused_kernel<.., SLAB>;
+    sd/diffusion.py:179 -> 199, 205 -> 294): x = sum_z slab[z] + bias (+ residual) must equal splitk_finalize's sum bit for
+    bit in its fp32 / fp16 copies, and the normalised output the fp64 GroupNorm of that sum."""
+    B = 2
+    g = torch.Generator().manual_seed(C + P + ksplit)
+    slabs = torch.randn((ksplit, B * P, C), generator=g) * (0.5 + torch.rand((C,), generator=g)) + 0.3 * torch.randn((C,), generator=g)
+    bias = torch.randn((C,), generator=g)
+    r = None if res is None else torch.randn((B * P, C), generator=g)
+    if res == "f16":
+        r = r.half()
+    gamma = 1 + 0.2 * torch.randn((C,), generator=g)
+    beta = 0.2 * torch.randn((C,), generator=g)
+    x = torch.zeros((B * P, C))
+    for z in range(ksplit):                      # fp32 sums in slab order, as the kernels add them
+        x = x + slabs[z]
+    x = x + bias
+    if r is not None:
+        x = x + r.float()
+    ref = F.group_norm(x.double().view(B, P, C).permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(B * P, C)
+    lib = N_.load()
+    sd, bd, gd, bed = slabs.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV)
+    rd = None if r is None else r.to(DEV)
+    y = torch.full((B * P, C), float("nan"), dtype=torch.float16, device=DEV)
+    o32 = torch.full((B * P, C), float("nan"), device=DEV)
+    o16 = torch.full((B * P, C), float("nan"), dtype=torch.float16, device=DEV)
+    N_.check(lib.sdmi_op_groupnorm_slab(N_.ptr(sd), ksplit, N_.ptr(bd), N_.ptr(rd), int(res == "f32"), C, B, P, N_.ptr(gd), N_.ptr(bed),
+                                        1e-5, silu, N_.ptr(y), N_.ptr(o32), N_.ptr(o16), N_.cur_stream()), "groupnorm_slab")
+    torch.cuda.synchronize()
+    assert torch.equal(o32.cpu(), x), "combined tensor differs from the slab-order fp32 sum"
+    assert torch.equal(o16.cpu(), x.half())
+    err = (y.float().cpu().double() - ref).abs().max().item()
+    G.log_metric(test="gn_slab", C=C, P=P, ksplit=ksplit, max_abs_err=err)
+    assert err < 4e-3, f"max abs err {err}"
 
 
 @pytest.mark.parametrize("P,offset", [(4096, 30.0), (1024, -30.0), (4096, 100.0), (64, 30.0)])
@@ -463,24 +496,17 @@ def test_upsample_conv_as_four_phase_convs(Bn, Hs, Ws, Cin, Cout, ksplit):
     nine = G.igemm(x.to(DEV), G.pack_conv(w.to(DEV)), B=Bn, Hs=Hs, Ws=Ws, Ho=2 * Hs, Wo=2 * Ws, ks=3, ups=1, bias=bias.to(DEV), out_f32=True)
     e9 = (nine.cpu().double() - ref).abs().max().item()
     rows = Bn * Hs * Ws
-    n_run = n_k = 0
-    for pc in _plain_cfgs() + _k_cfgs():
+    n_run = 0
+    for pc in _plain_cfgs():
         bm = G.gemm_tile(pc)[0]
         if rows % bm:
             continue
-        try:
-            got = G.igemm(x.to(DEV), w4, B=Bn, Hs=Hs, Ws=Ws, Ho=Hs, Wo=Ws, ks=2, bias=bias.to(DEV), out_f32=True, cfg=pc, ksplit=ksplit,
-                          phase2=1, img_rows=rows, w_img_stride=Cout * 4 * Cin, n_out=Cout)
-        except ValueError as exc:
-            assert pc in _k_cfgs() and ("not applicable" in str(exc) or "LDS" in str(exc)), exc
-            continue
+        got = G.igemm(x.to(DEV), w4, B=Bn, Hs=Hs, Ws=Ws, Ho=Hs, Wo=Ws, ks=2, bias=bias.to(DEV), out_f32=True, cfg=pc, ksplit=ksplit,
+                      phase2=1, img_rows=rows, w_img_stride=Cout * 4 * Cin, n_out=Cout)
         err = (got.cpu().double() - ref).abs().max().item()
         assert err < max(2 * e9, 4e-3), f"cfg {pc}: max abs err {err} (9-tap path: {e9})"
         n_run += 1
-        n_k += pc in _k_cfgs()
     assert n_run >= 8
-    if Ws % 8 == 0 and rows % 128 == 0:
-        assert n_k > 0, "the general halo kernel did not run the phase-decomposed upsample conv"
     G.log_metric(test="ups_phase", rows=rows, C=Cin, nine_tap_err=e9)
 
 

@@ -81,7 +81,7 @@ def bench(H, C0, C1, Co, X, phase, fams, splits, reps=6, B=2):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    fams = "kht"
+    fams = "ht"
     for i, arg in enumerate(sys.argv):
         if arg == "--fam":
             fams = sys.argv[i + 1].replace(",", "")
