@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--stream-f16", action="store_true", help="fp16 residual stream (default fp32 stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image-latency", action="store_true", help="skip the end-to-end generate() latency leg")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="throughput mode, reported beside the single-chain headline: this many independent denoising loops "
+                         "(lanes over ONE copy of the packed weights) run concurrently on the GPU, one HIP stream each")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also time BASELINE configs[0] end to end on the host CPU (oracle CLIP x2 + 20 CFG steps + VAE "
@@ -167,7 +170,10 @@ def main():
         elapsed = replicas.max_over_ranks(elapsed, device=dev)
     launches = h.last_launch_count + 1
 
-    # ---- roofline: per-launch HIP events on the forward's own stream, same process, after the timed region
+    # ---- roofline: per-launch HIP events on the forward's own stream, same process, after the timed region.
+    # ONE family definition everywhere (this line, tools/join_trace.py, profiles/r03_*): "mfma" = the GEMM kernels that run
+    # MFMAs (igemm_kernel, conv3_halo_kernel, b2b_kernel); the splitk_finalize launches that complete split-K GEMMs are
+    # reported on their own and as "with_finalize".
     roof = None
     if rank == 0:
         h.profile(True)
@@ -176,52 +182,102 @@ def main():
         torch.cuda.synchronize()
         pr = h.profile_read()
         h.profile(False)
-        ig = pr["igemm"]
-        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        mf, fin = pr["mfma"], pr["finalize"]
+        achieved = mf["flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
+        achieved_fin = mf["flops"] / ((mf["ms"] + fin["ms"]) * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
         scale = (hw / 64.0) ** 2
-        # HBM/fabric bytes per step of the same kernel family and its MFMA-busy fraction come from separate rocprofv3 --pmc
-        # passes around THIS command (tools/profile_r02.sh; FETCH_SIZE x2: gfx950 correction), committed under profiles/.
-        # They are only quoted when that profile saw the launch structure this run has (same launches per step): a
-        # profile of other kernels is refused rather than reported stale.
+        # HBM/fabric bytes per step and the MFMA-busy fraction come from separate rocprofv3 --pmc passes around THIS command
+        # (tools/profile_round.sh; FETCH_SIZE x2: gfx950 correction), committed under profiles/.  They are only quoted when
+        # that profile saw the launch structure this run has (same launches per step): a profile of other kernels is refused
+        # rather than reported stale.
         launches_now = h.last_launch_count + 1
-        traffic, traffic_src, mfma_busy, mfma_src = None, None, None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_by_shape.json")
+        traffic = traffic_fin = traffic_step = mfma_busy = None
+        traffic_src = mfma_src = None
+        tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic_by_shape.json")
         if hw == 64 and os.path.exists(tpath):
             with open(tpath) as tf:
                 tj = json.load(tf)
             if tj.get("bench_launches_per_step") == launches_now:
-                traffic = round(tj["families"]["igemm"]["hbm_bytes"] / 1e9, 3)
-                traffic_src = "profiles/r02_hbm_traffic_by_shape.json (GB per step over the family's launches)"
+                fam = tj["families"]
+                traffic = round(fam["mfma"]["hbm_bytes"] / 1e9, 3)
+                traffic_fin = round((fam["mfma"]["hbm_bytes"] + fam.get("finalize", {}).get("hbm_bytes", 0.0)) / 1e9, 3)
+                traffic_step = round(tj["whole_step"]["hbm_bytes"] / 1e9, 3)
+                traffic_src = "profiles/r03_hbm_traffic_by_shape.json (GB per step, FETCH_SIZE x2 + WRITE_SIZE over the family's launches)"
             else:
-                traffic_src = (f"refused: profiles/r02_hbm_traffic_by_shape.json was taken at {tj.get('bench_launches_per_step')} "
+                traffic_src = (f"refused: profiles/r03_hbm_traffic_by_shape.json was taken at {tj.get('bench_launches_per_step')} "
                                f"launches/step, this run has {launches_now}")
-        mpath = os.path.join(ROOT, "profiles", "r02_mfma_busy.json")
+        mpath = os.path.join(ROOT, "profiles", "r03_mfma_busy.json")
         if hw == 64 and os.path.exists(mpath):
-            with open(mpath) as mf:
-                mj = json.load(mf)
+            with open(mpath) as mfh:
+                mj = json.load(mfh)
             if mj.get("bench_launches_per_step") == launches_now:
-                mfma_busy = round(mj["families"]["igemm"]["mfma_busy_frac_of_chip"], 4)
-                mfma_src = "profiles/r02_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family's launches"
+                mfma_busy = round(mj["families"]["mfma"]["mfma_busy_frac_of_chip"], 4)
+                mfma_src = "profiles/r03_mfma_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) over the family's launches"
             else:
                 mfma_src = f"refused: profile taken at {mj.get('bench_launches_per_step')} launches/step, this run has {launches_now}"
         roof = {
-            "bound": "mfma", "kernel": "igemm_kernel + conv3_halo_kernel (all conv3x3/conv1x1/linear launches of a step)",
+            "bound": "mfma", "kernel": "MFMA GEMM family: igemm_kernel + conv3_halo_kernel + b2b_kernel (every conv3x3 / conv1x1 / linear of a step)",
             "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_TFLOPS_F16, 4), "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src,
             "traffic": traffic, "traffic_unit": "GB/step", "traffic_source": traffic_src,
             "algorithmic_bytes_per_step_GB": 1.62,
             "algorithmic_bytes_note": "SURVEY 8d floor: the live fp16 weights once per step; activations (2.6 GB/step if every "
                                       "GEMM input/output round-tripped HBM once) are not part of the floor",
-            "launches_per_step": ig["launches"] // nprof,
-            "gflop_per_step": round(ig["flops"] / nprof / 1e9, 2),
-            "ms_per_step": round(ig["ms"] / nprof, 3),
+            "launches_per_step": mf["launches"] // nprof,
+            "gflop_per_step": round(mf["flops"] / nprof / 1e9, 2),
+            "ms_per_step": round(mf["ms"] / nprof, 3),
+            "with_finalize": {"achieved": round(achieved_fin, 2), "frac": round(achieved_fin / PEAK_TFLOPS_F16, 4),
+                              "launches_per_step": (mf["launches"] + fin["launches"]) // nprof,
+                              "ms_per_step": round((mf["ms"] + fin["ms"]) / nprof, 3), "traffic": traffic_fin,
+                              "finalize_launches_per_step": fin["launches"] // nprof,
+                              "finalize_ms_per_step": round(fin["ms"] / nprof, 3)},
             "attention": {"ms_per_step": round(pr["attention"]["ms"] / nprof, 3),
                           "tflops": round(pr["attention"]["flops"] / max(pr["attention"]["ms"], 1e-9) / 1e9, 2),
                           "launches_per_step": pr["attention"]["launches"] // nprof},
             "norm_ms_per_step": round(pr["norm"]["ms"] / nprof, 3),
+            "norm_launches_per_step": pr["norm"]["launches"] // nprof,
             "whole_step": {"algorithmic_gflop": round(ALGO_GFLOP_512 * scale, 2) if hw == 64 else None,
-                           "achieved_tflops": round(ALGO_GFLOP_512 * args.steps / (ev_ms * 1e-3) / 1e3, 2) if hw == 64 else None},
+                           "achieved_tflops": round(ALGO_GFLOP_512 * args.steps / (ev_ms * 1e-3) / 1e3, 2) if hw == 64 else None,
+                           "traffic": traffic_step, "launches_per_step": launches_now},
         }
+
+    # ---- throughput mode (--chains C): C independent denoising loops on C streams over one copy of the packed weights.
+    # Reported beside the headline, never as `value`: a single image's latency does not change, a BATCH of prompts per GPU
+    # (BASELINE configs[3]) finishes sooner because the chains fill each other's per-launch latency.
+    chains = None
+    if rank == 0 and world == 1 and args.chains > 1:
+        lanes = [model] + [model.lane() for _ in range(args.chains - 1)]
+        streams = [torch.cuda.Stream(device=dev) for _ in lanes]
+        lats = []
+        for k, (ln, stc) in enumerate(zip(lanes, streams)):
+            with torch.cuda.stream(stc):
+                ln.set_context(ctx)
+                ln.set_schedule(temb)
+                lats.append(lat0.clone())
+        torch.cuda.synchronize()
+
+        def run_chains(n_steps):
+            for i in range(n_steps):
+                j = i % 50
+                for ln, stc, lt in zip(lanes, streams, lats):
+                    with torch.cuda.stream(stc):
+                        if j == 0:
+                            lt.copy_(lat0)
+                        ln.handle().denoise_step(lt, j, True, 7.5, noise[j] if ts[j] > 0 else None, coefs[j])
+
+        run_chains(args.warmup)
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        run_chains(args.steps)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - tc0
+        chains = {"chains": args.chains, "steps_per_s_aggregate": round(args.chains * args.steps / dtc, 3),
+                  "ms_per_step_per_chain": round(dtc / args.steps * 1e3, 3),
+                  "note": "independent prompts on one GPU: lanes of one packed-weight arena (Diffusion.lane / sdmi_unet_clone), one "
+                          "HIP stream each, steps enqueued alternately by one host thread; replicas.run_prompts(streams_per_gpu=C) "
+                          "is the generate()-level form"}
+        model.set_context(ctx)
+        model.set_schedule(temb)
 
     # ---- 50-step image latency: the drop-in generate() end to end (CLIP x2 + 50 fused steps + VAE decode)
     image_latency = None
@@ -321,6 +377,8 @@ def main():
                                          "~/.cache/sdmi/plans-<library hash>.txt; only shapes in neither are timed"}},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if chains is not None:
+            out["throughput_mode"] = chains
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -52,6 +52,10 @@ int sdmi_version(void);
  * and its activation arena.  Synchronous. */
 int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, sdmi_unet** out);
 void sdmi_unet_destroy(sdmi_unet* u);
+/* A second lane over the SAME packed weights (borrowed: `src` must outlive the clone and is destroyed after it): own
+ * activation arena, split-K slabs, context / schedule buffers.  Two lanes driven on two streams run two independent
+ * denoising loops (sd/pipeline.py:146: every generate() is independent) concurrently on one GPU. */
+int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out);
 
 /* Hoists the 32 loop-invariant cross-attention K/V projections of the context
  * (sd/attention.py:221-222 via sd/diffusion.py:338).  ctx_dev: (batch, n_tokens, 768) fp32. */
@@ -92,8 +96,9 @@ int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, con
                         float* out_dev, void* stream);
 
 /* Per-launch HIP-event profiling of the forward (bench.py roofline): enable, run forwards, then read
- * summed milliseconds / algorithmic FLOPs / launch counts for class 0 = implicit-GEMM conv+linear,
- * 1 = flash attention, 2 = norms.  Events are recorded on the forward's own stream. */
+ * summed milliseconds / algorithmic FLOPs / launch counts into arrays of FOUR classes: 0 = MFMA GEMM kernels
+ * (implicit-GEMM conv + linear, halo conv, back-to-back GEMM), 1 = flash attention, 2 = norms, 3 = splitk_finalize (the
+ * combine launches of split-K GEMMs).  Events are recorded on the forward's own stream. */
 int sdmi_unet_profile(sdmi_unet* u, int enable);
 int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_class, int* launches_by_class);
 
@@ -161,10 +166,6 @@ typedef struct sdmi_gemm_desc {
   float* rowstat;
   const float* ln_stat; int ln_ntn; const float* ln_g; int ln_c; float ln_eps;
   int out_t_perm;   /* 1: out_t's key axis in the quad-permuted order sdmi_op_attention reads; 0: natural order */
-  /* GroupNorm(32)(+SiLU) of the A operand fused into a 3x3 stride-1 conv (sd/diffusion.py:173-179,199-205): a0 | a1 are
-   * the RAW activations, gn_partial the statistics sdmi_op_gn_stats wrote ([B][gn_nchunk][32][2] fp32), gn_gamma /
-   * gn_beta the (c0+c1) affine parameters.  Only the "g..." configs accept it (cfg < 0 picks one); NULL: plain conv. */
-  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
   /* act = 2: the epilogue is a row softmax in the log2 domain, out = 2^(v - max) / sum over each 128-column n-tile with
    * columns >= sm_valid (per tile) masked: one attention head per tile (128-wide configs, fp16 out, full tiles).
    * img_rows > 0: per-image weights, rows [i*img_rows, (i+1)*img_rows) use w + i*w_img_stride (elements, row stride ldw
@@ -248,7 +249,7 @@ int sdmi_op_groupnorm_slab(const float* slab, int ksplit, const float* bias, con
 int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,
                       void* y_f16, void* stream);
 /* GroupNorm statistics only: per (image, pixel chunk, group) partial {sum, sum of squares} into partial_out
- * ([B][nchunk][32][2] fp32, nchunk = sdmi_gn_num_chunks(P)); consumed by sdmi_op_gemm's gn_partial. */
+ * ([B][nchunk][32][2] fp32, nchunk = sdmi_gn_num_chunks(P)); consumed by sdmi_op_b2b's gn_partial. */
 int sdmi_gn_num_chunks(int P);
 int sdmi_op_gn_stats(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, float* partial_out, void* stream);
 

@@ -34,8 +34,6 @@ class GemmDesc(C.Structure):
                 ("x0", C.c_void_p), ("x1", C.c_void_p), ("cx0", C.c_int), ("cx1", C.c_int),
                 ("rowstat", C.c_void_p), ("ln_stat", C.c_void_p), ("ln_ntn", C.c_int), ("ln_g", C.c_void_p),
                 ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int),
-                ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
-                ("gn_eps", C.c_float), ("gn_silu", C.c_int),
                 ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
                 ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int),
                 ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p)]
@@ -58,6 +56,7 @@ _SIGNATURES = {
     "sdmi_last_error": (C.c_char_p, []),
     "sdmi_version": (C.c_int, []),
     "sdmi_unet_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sdmi_unet_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "sdmi_unet_destroy": (None, [C.c_void_p]),
     "sdmi_unet_set_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sdmi_unet_set_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -327,10 +326,29 @@ class UNetHandle(_DeviceBound):
         self._lib = lib
         self.flags = flags
 
+    def clone(self) -> "UNetHandle":
+        """A second lane over the same packed weights (own arena / slabs / context): drive it on another stream to run a
+        second, independent denoising loop concurrently.  The clone keeps this handle alive."""
+        other = UNetHandle.__new__(UNetHandle)
+        other._dev, other._lib, other.flags = self._dev, self._lib, self.flags
+        other._parent = self
+        self._children = getattr(self, "_children", 0) + 1
+        h = C.c_void_p()
+        with self._guard():
+            check(self._lib.sdmi_unet_clone(self._h, C.byref(h)), "sdmi_unet_clone")
+        other._h = h
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_children", 0) > 0:
+                raise RuntimeError("UNetHandle.close(): lanes cloned from this handle are still open (they borrow its weights)")
             self._lib.sdmi_unet_destroy(self._h)
             self._h = None
+            parent = getattr(self, "_parent", None)
+            if parent is not None:
+                parent._children -= 1
+                self._parent = None
 
     def __del__(self):
         try:
@@ -396,11 +414,11 @@ class UNetHandle(_DeviceBound):
         check(self._lib.sdmi_unet_profile(self._h, int(enable)), "sdmi_unet_profile")
 
     def profile_read(self):
-        ms = (C.c_double * 3)()
-        fl = (C.c_double * 3)()
-        nl = (C.c_int * 3)()
+        ms = (C.c_double * 4)()
+        fl = (C.c_double * 4)()
+        nl = (C.c_int * 4)()
         check(self._lib.sdmi_unet_profile_read(self._h, ms, fl, nl), "sdmi_unet_profile_read")
-        names = ("igemm", "attention", "norm")
+        names = ("mfma", "attention", "norm", "finalize")
         return {n: dict(ms=ms[i], flops=fl[i], launches=nl[i]) for i, n in enumerate(names)}
 
     @property

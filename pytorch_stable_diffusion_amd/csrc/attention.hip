@@ -48,6 +48,7 @@ struct ACfg {
   // MFMAs per 64-key tile in the S = 4096 self-attention.
   static constexpr bool SPARE = (D % 16) != 0;
   static constexpr int LDS = 2 * STAGE;
+  static constexpr int EXTRA = SPARE ? 16 : 0;     // the K-side bias fragment behind the stages
 };
 
 template <int D, bool SPLIT>
@@ -165,6 +166,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   for (int e = 0; e < 8; ++e) { kbias[e] = (f16)0.f; qbias[e] = (f16)0.f; }
   // SPARE: k-index 40 is element 0 of the half-wave h = 1 in the last k16 step; otherwise k-index 0 of the extra step (h = 0)
   if (h == (C::SPARE ? 1 : 0)) kbias[0] = (f16)1.f;
+  // SPARE: the h = 1 lanes of the last k16 step read their K fragment {1, 0, ..., 0} from 16 bytes behind the K/V stages (one
+  // select on the LDS address instead of four on the loaded registers); visible after the first __syncthreads()
+  const char* const kbias_lds = smem + 2 * STAGE2;
+  if (C::SPARE && tid == 0) {
+    f16x8 one;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) one[e] = (f16)0.f;
+    one[0] = (f16)1.f;
+    *(f16x8*)(smem + 2 * STAGE2) = one;
+  }
 
   // one 64-key tile: S'^T = K Q'^T - m_run, online softmax, O^T += V^T P^T.  FIRST: tile 0 (m_run not set yet).
   auto tile_body = [&](auto masked_tag, auto first_tag, int t, int cur) {
@@ -179,8 +190,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) {
-        f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r) * (D * 2) + koff[s]);
-        if (C::SPARE && s == C::NS - 1 && h == 1) kf = kbias;       // padding columns of K: {1, 0, ...} against Q's {-m_run, 0, ...}
+        const char* ka = Ks + (kb * 32 + r) * (D * 2) + koff[s];
+        if (C::SPARE && s == C::NS - 1) ka = h == 1 ? kbias_lds : ka;       // padding columns of K: {1, 0, ...} against Q's {-m_run, 0, ...}
+        const f16x8 kf = *(const f16x8*)ka;
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
       }
       if constexpr (!FIRST && !C::SPARE) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kbias, qbias, sacc[kb], 0, 0, 0);
@@ -207,7 +219,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       mx1 = fmaxf(fmaxf(mx1, sacc[1][e]), sacc[1][e + 1]);
     }
     float mx = fmaxf(fmaxf(mx0, sacc[0][15]), fmaxf(mx1, sacc[1][15]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    {   // lane ^ 32 exchange on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute + wait, ~120 cycles of
+        // the tile's dependent chain): swapping a register with a copy of itself leaves {lower half, lower half} in one and
+        // {upper, upper} in the other
+      const unsigned mb = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     if (FIRST || __builtin_expect(__any(mx > 8.f), 0)) {
       float d = FIRST ? mx : fmaxf(mx, 0.f);
       if (!(d > -60000.f)) d = 0.f;                       // a query with no valid key in this tile keeps its max
@@ -337,20 +355,20 @@ int launch(const AttnArgs& a, hipStream_t st) {
   SDMI_CHECK_HIP(hipGetDevice(&dev));
   SDMI_REQUIRE(dev >= 0 && dev < 16, "attention: device index %d out of range", dev);
   if (!attr_done[dev]) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + C::EXTRA));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS + C::EXTRA));
     attr_done[dev] = true;
   }
   // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
   static const bool split_on = !(getenv("SDMI_ATTN_SPLIT") && atoi(getenv("SDMI_ATTN_SPLIT")) == 0);
   // (at S = 4096 the split form stages four times the K/V bytes per query and loses: attention 0.646 vs 0.617 ms/step)
   static const int split_max = getenv("SDMI_ATTN_SPLIT_MAXS") ? atoi(getenv("SDMI_ATTN_SPLIT_MAXS")) : 1024;
-  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS <= 160 * 1024) {
+  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS + C::EXTRA <= 160 * 1024) {
     dim3 grid(a.Sq / 64, a.B * a.H);
-    hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS, st, a);
+    hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
   } else {
     dim3 grid((a.Sq + 127) / 128, a.B * a.H);
-    hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), C::LDS, st, a);
+    hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), C::LDS + C::EXTRA, st, a);
   }
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;

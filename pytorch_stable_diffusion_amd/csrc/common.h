@@ -114,17 +114,13 @@ struct GemmArgs {
   // partial sums, workgroups (kz = 0, tn = 0) also write {mean, rstd} of their rows to ln_out[M][2], and splitk_finalize
   // applies  rstd (sum of folded slabs - mean g) + sum of plain slabs + bias (+ res)
   float* ln_out;
-  // GroupNorm(32) (+SiLU) of the A operand fused into the 3x3 conv (conv3_gn_kernel; sd/diffusion.py:173-179,199-205):
-  // a0 | a1 are the RAW activations; gn_partial = gn_stats_kernel's per-chunk {sum, sum of squares} per group
-  // ([B][gn_nchunk][32][2]), reduced in the conv's prologue; y = silu(x * (rstd gamma) + (beta - mean rstd gamma)) is
-  // applied once per staged halo chunk in LDS, and the 9 taps read the normalised image.  nullptr: plain conv.
-  const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_silu;
   int no_finalize;     // split-K: leave the partial sums in the slabs, launch no splitk_finalize
 };
 
-// cfg < 0: heuristic.  ksplit_out: effective split-K factor of the launch.  a.no_finalize = 1: a split-K launch only writes
-// its slabs (the caller combines them, e.g. sdmi_launch_groupnorm with GnArgs::slab)
-int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out = nullptr);
+// cfg < 0: heuristic.  ksplit_out / ksteps_per_out: effective split-K factor and K-steps per slice of the launch.
+// a.no_finalize = 1: a split-K launch only writes its slabs; the caller combines them (sdmi_launch_splitk_finalize with
+// those two values filled in, or sdmi_launch_groupnorm with GnArgs::slab)
+int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out = nullptr, int* ksteps_per_out = nullptr);
 
 // Back-to-back GEMM of the 320-channel attention blocks (b2b.hip): S = A1 W1^T + b1 + R1, then the next Linear with the
 // LayerNorm of S folded in, in one launch.  All matrices have 320 columns / output rows.
@@ -199,7 +195,7 @@ struct GnArgs {
 int sdmi_gn_nchunk(int P);
 int sdmi_gn_launches(const GnArgs& a);
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st);
-int sdmi_launch_gn_stats(const GnArgs& a, hipStream_t st);   // statistics only (consumer: conv3_gn_kernel via GemmArgs::gn_partial)
+int sdmi_launch_gn_stats(const GnArgs& a, hipStream_t st);   // statistics only (consumer: b2b_kernel via B2bArgs::gn_partial)
 
 struct LnArgs {
   const void* x; int in_f32;  // [M][C]

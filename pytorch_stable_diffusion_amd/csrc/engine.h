@@ -247,14 +247,15 @@ struct Engine {
   int flush_pending() {
     if (!pend) return SDMI_OK;
     pend = false;
-    prof_begin(2, 0.0);
+    prof_begin(3, 0.0);
     TRY(sdmi_launch_splitk_finalize(pend_args, st));
     prof_end();
     launches += 1;
     log_launch("finalize M=%d N=%d K=%d split=%d", pend_args.M, pend_args.N, pend_args.K, pend_args.ksplit);
     return SDMI_OK;
   }
-  // optional per-launch HIP-event profiling (bench roofline): class 0 = igemm, 1 = attention, 2 = other
+  // optional per-launch HIP-event profiling (bench roofline): class 0 = MFMA GEMM kernels (igemm / halo conv / back-to-back),
+  // 1 = attention, 2 = norms, 3 = splitk_finalize
   bool profiling = false;
   struct ProfRec { hipEvent_t e0, e1; int cls; double flops; };
   std::vector<ProfRec> prof;
@@ -560,7 +561,7 @@ struct Engine {
   int plan_of(GemmArgs& a, std::map<ShapeKey, Plan>::iterator* out) {
     a.zero = zero;
     a.slab = slab;
-    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 1024 * (a.gn_partial != nullptr) + 2048 * (a.img_rows != 0),
+    ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 2048 * (a.img_rows != 0),
                  a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
     if (it == plans.end()) {
@@ -601,7 +602,7 @@ struct Engine {
     a.ksplit = it->second.ksplit;
     defer = defer && defer_on() && a.ksplit > 1 && !a.outT && !a.act && !a.phase2 && a.cs_hi == 0 && !a.ln_stat && !a.rowstat &&
             a.ldc == a.N && (!a.res || a.ldr == a.N) && a.Ho * a.Wo <= defer_max_px();
-    a.no_finalize = defer ? 1 : 0;
+    a.no_finalize = 1;                     // the combine is this function's own launch (timed as its own class) or deferred
     if (rs) {
       static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
       rs->ptr = nullptr;
@@ -617,12 +618,22 @@ struct Engine {
     }
     it->second.calls += 1;
     it->second.flops = 2.0 * a.M * a.N * a.K;
-    int ks_eff = 1;
+    int ks_eff = 1, kper = 0;
     prof_begin(0, 2.0 * a.M * a.N * a.K);
-    TRY(sdmi_launch_gemm(a, it->second.cfg, st, &ks_eff));
+    TRY(sdmi_launch_gemm(a, it->second.cfg, st, &ks_eff, &kper));
     prof_end();
     const bool deferred = defer && ks_eff > 1;
-    if (deferred) { pend = true; pend_args = a; pend_args.ksplit = ks_eff; pend_args.no_finalize = 0; pend_key = a.out; }
+    if (ks_eff > 1) {
+      GemmArgs f = a;
+      f.ksplit = ks_eff; f.no_finalize = 0;
+      f.ksteps_per = kper;                 // as the launcher split K (splitk_finalize needs it for the partial LayerNorm fold)
+      if (deferred) { pend = true; pend_args = f; pend_key = a.out; }
+      else {
+        prof_begin(3, 0.0);
+        TRY(sdmi_launch_splitk_finalize(f, st));
+        prof_end();
+      }
+    }
     const int nl = (ks_eff > 1 && !deferred) ? 2 : 1;
     launches += nl;
     if (logging) {
@@ -765,32 +776,6 @@ struct Engine {
     else { log_launch("gn_stats C=%d P=%d B=%d", C, g.P, g.B); log_launch("gn_apply C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu); }
     return SDMI_OK;
   }
-  // ---- GroupNorm(+SiLU) fused into the following 3x3 conv (conv3_gn_kernel) --------------------------------
-  // gn_fuse (SDMI_GN_FUSE): 0 off, 1 auto (per shape, whichever pipeline's plans are faster), 2 always when a g-config fits
-  int gn_fuse = getenv("SDMI_GN_FUSE") ? atoi(getenv("SDMI_GN_FUSE")) : 1;
-  void set_gn(GemmArgs& a, const NormW& w, float eps, int silu) const {
-    a.gn_partial = gn_partial; a.gn_nchunk = sdmi_gn_nchunk(a.Hs * a.Ws);
-    a.gn_gamma = w.gamma; a.gn_beta = w.beta; a.gn_eps = eps; a.gn_silu = silu;
-  }
-  bool gn_candidate(const GemmArgs& a) const {
-    if (gn_fuse == 0) return false;
-    for (int c = sdmi_gemm_num_plain_cfgs(); c < sdmi_gemm_num_cfgs(); ++c)
-      if (sdmi_gemm_cfg_applicable(a, c)) return true;
-    return false;
-  }
-  // Auto mode: fuse when the fused conv's plan is faster than the best unfused conv plan + the gn_apply launch it
-  // replaces (modelled as 3.5 us + bytes / 2.8 TB/s: measured 8.9 us for C=320 at 64x64, 12.3 us for C=640, 7.1 us for
-  // C=640 at 32x32).  Both argument sets must be complete (the plans may be timed right here).
-  int gn_fuse_wins(GemmArgs fused, GemmArgs unfused, bool in_f32, bool* win) {
-    if (gn_fuse == 2 || !tune) { *win = true; return SDMI_OK; }
-    std::map<ShapeKey, Plan>::iterator pf, pu;
-    TRY(plan_of(fused, &pf));
-    TRY(plan_of(unfused, &pu));
-    const double elems = (double)fused.M * (fused.C0 + fused.C1) / ((double)fused.stride * fused.stride);
-    const double t_apply = 3.5 + elems * (in_f32 ? 6.0 : 4.0) / 2.8e6;
-    *win = pf->second.us < pu->second.us + t_apply;
-    return SDMI_OK;
-  }
   int gn_stats(const Act& x, const Act* x1) {
     TRY(flush_pending());
     GnArgs g;
@@ -834,45 +819,16 @@ struct Engine {
     Act t0, h, t1, sk;
     TRY(new_act(x.B, x.H, x.W, r.cout, false, &h));
     {
-      // GroupNorm -> SiLU -> conv_feature (sd/diffusion.py:173-179): fused (the conv normalises its own A operand from
-      // the raw stream) or the norm writes a normalised tensor the conv re-reads, whichever plan is faster
-      GemmArgs a = base_args(x, x1, r.conv1, x.H, x.W, 1, 0);
-      set_gn(a, r.gn1, 1e-5f, 1);
+      // GroupNorm -> SiLU -> conv_feature (sd/diffusion.py:173-179): the norm writes the normalised fp16 tensor (the virtual
+      // concat of x | x1 materialises here), the conv reads it.  (A conv that normalised its own A operand in LDS,
+      // conv3_gn_kernel, was built in round 2 and lost to this pair on every 512x512 shape: removed in round 3.)
+      TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
+      GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
       a.bias = bias1; a.out = h.h; a.ldc = h.C;
-      bool fuse = false;
-      if (gn_candidate(a)) {
-        TRY(new_act(x.B, x.H, x.W, cin, false, &t0));
-        GemmArgs u = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
-        u.bias = bias1; u.out = h.h; u.ldc = h.C;
-        TRY(gn_fuse_wins(a, u, x.f != nullptr, &fuse));
-      }
-      if (fuse) {
-        TRY(gn_stats(x, x1));
-      } else {
-        TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
-        a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
-        a.bias = bias1; a.out = h.h; a.ldc = h.C;
-      }
       pend_keep16 = false;                     // h has one reader: groupnorm_merged
       TRY(gemm(a, nullptr, /*defer=*/true));
     }
     TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
-    GemmArgs a = base_args(h, nullptr, r.conv2, x.H, x.W, 1, 0);
-    // finishes conv_merged's arguments (skip segment or residual, outputs) on `g`; the skip GEMM itself is launched by
-    // the caller when the skip conv is not fused
-    auto finish = [&](GemmArgs& g) {
-      if (r.has_skip && r.w2s) {
-        g.x0 = x.h; g.X0 = x.C;
-        if (x1) { g.x1 = x1->h; g.X1 = x1->C; }
-        g.K += g.X0 + g.X1;
-        g.w = r.w2s; g.bias = r.bias2s;
-      } else if (r.has_skip) {
-        set_res(g, sk);
-      } else {
-        set_res(g, x);
-      }
-      set_out(g, *y);
-    };
     if (r.has_skip && !r.w2s) {
       TRY(new_act(x.B, x.H, x.W, r.cout, true, &sk));
       GemmArgs s = base_args(x, x1, r.skip, x.H, x.W, 1, 0);
@@ -880,22 +836,19 @@ struct Engine {
       s.ldc = sk.C;
       TRY(gemm(s));
     }
-    set_gn(a, r.gn2, 1e-5f, 1);
-    finish(a);
-    bool fuse2 = false;
-    if (gn_candidate(a)) {
-      TRY(new_act(x.B, x.H, x.W, r.cout, false, &t1));
-      GemmArgs u = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
-      finish(u);
-      TRY(gn_fuse_wins(a, u, false, &fuse2));
-    }
-    if (fuse2) {
-      TRY(gn_stats(h, nullptr));
+    TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
+    GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+    if (r.has_skip && r.w2s) {                 // the 1x1 skip conv as an extra K-range of conv_merged (sd/diffusion.py:143,209)
+      a.x0 = x.h; a.X0 = x.C;
+      if (x1) { a.x1 = x1->h; a.X1 = x1->C; }
+      a.K += a.X0 + a.X1;
+      a.w = r.w2s; a.bias = r.bias2s;
+    } else if (r.has_skip) {
+      set_res(a, sk);
     } else {
-      TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
-      a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
-      finish(a);
+      set_res(a, x);
     }
+    set_out(a, *y);
     pend_keep16 = true;
     TRY(gemm(a, nullptr, /*defer=*/y_to_gn));
     return SDMI_OK;

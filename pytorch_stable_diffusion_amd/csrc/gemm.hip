@@ -976,459 +976,6 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #endif
 }
 
-// =============================================================================================
-// 3x3 / stride-1 convolution with halo reuse AND the preceding GroupNorm(+SiLU) fused into the A operand
-// (reference: x = F.silu(groupnorm(x)); x = conv(x), sd/diffusion.py:173-179,199-205), plus the ResBlock's 1x1 skip conv
-// as extra K chunks (sd/diffusion.py:143,209).
-//
-// Three wave roles per workgroup (NW waves each, one of each per SIMD), one s_barrier per tap interval:
-//   MFMA waves   ds_read + v_mfma over the normalised halo and the weight ring (as conv3_halo_kernel);
-//   DMA waves    LDS-DMA: one BN x 64 weight tile per interval (NS-deep ring) and, spread over a chunk's intervals, the
-//                RAW halo of chunk c+2; counted vmcnt leaves exactly the newest interval's DMAs in flight;
-//   X waves      normalise halo(c+1) -- landed raw during chunk c-1 -- IN PLACE while chunk c is multiplied: one
-//                8-pixel x 64-channel piece per wave per interval, y = silu(a_c x + b_c), a = rstd_g gamma_c,
-//                b = beta_c - mean_g a, fp32 math, fp16 storage.  Padding stays zero: side columns are never written,
-//                out-of-image rows are DMA'd from zeros and skipped.
-// K is walked chunk-major: a chunk = 64 input channels; a MAIN chunk has 9 tap intervals, an EXTRA chunk (skip conv, raw
-// x at the output pixel) one (centre tap).  Three halo buffers rotate (DMA | normalise | multiply).  Split-K splits at
-// chunk boundaries.  The per-(image, group) statistics come from gn_stats_kernel's partial sums, reduced in the prologue
-// exactly like gn_apply_kernel does; the per-chunk (a, b) table is built by MFMA wave 0 from gamma / beta it loads one
-// chunk ahead.  Values read from the kernel-argument segment inside the interval path cost two scalar-load round trips
-// per interval (measured: +9 us on a 30 us conv), so everything the hot loops need is computed once per chunk / per
-// kernel and pinned in registers (PIN_S).
-template <int BM_, int BN_, int WM_, int WN_, int DW_ = 1>
-struct GCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = 3;
-  static constexpr int NW = WM * WN;              // MFMA waves = X waves
-  static constexpr int ND = DW_ * NW;             // DMA waves (DW_ = 2: two per SIMD, each issues half of an interval's DMAs)
-  static constexpr int NT = 64 * (2 * NW + ND);
-  static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
-  static constexpr int B_BYTES = BN * 128, RB = BN * 8 / (64 * ND);
-  static constexpr int MAXP = 8;                  // halo pieces per X wave per chunk (launcher checks the shape); per DMA wave: MAXP / DW_
-  static constexpr int MAXD = MAXP / DW_;
-  static_assert(BN * 8 % (64 * ND) == 0, "weight staging must divide evenly over the DMA waves");
-  static constexpr int TAIL = 1024 + 4096 + 256 + 1024;   // (a,b) table x2, s_red (fp64), s_mean/s_rstd, dump
-};
-
-#define PIN_S(x) asm volatile("" : "+s"(x))       // the value now lives in a register: no re-read of the kernarg segment
-
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  // waits until at most n vector-memory operations are outstanding (fewer is always safe)
-  switch (n < 12 ? n : 12) {
-    case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
-    case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-    case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
-    case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-    default: wait_vmcnt<12>(); break;
-  }
-}
-
-// y = silu(a x + b) (or a x + b) on 8 fp16 values; (a, b) pairs interleaved in t0..t3
-__device__ __forceinline__ f16x8 gn_apply8(f16x8 v, f32x4 t0, f32x4 t1, f32x4 t2, f32x4 t3, bool silu) {
-  const float a_[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3[0], t3[2]};
-  const float b_[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3[1], t3[3]};
-  f16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float y = (float)v[e] * a_[e] + b_[e];
-    if (silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
-    o[e] = (f16)y;
-  }
-  return o;
-}
-
-template <class C>
-__global__ __launch_bounds__(C::NT) void conv3_gn_kernel(GemmArgs p, int halo_bytes) {
-  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, ND = C::ND, NT = C::NT, NS = C::NS;
-  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, MAXP = C::MAXP, MAXD = C::MAXD, NALL = 2 * NW + ND;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave_id < NW ? 0 : (wave_id < NW + ND ? 1 : 2);   // 0 MFMA, 1 DMA, 2 X (normalise)
-  const int wave = role == 0 ? wave_id : (role == 1 ? wave_id - NW : wave_id - NW - ND);
-  const int wm = wave / C::WN, wn = wave % C::WN;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles = tiles_n * (p.M / BM);
-  int kz, tile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    kz = L / tiles;
-    tile = L - kz * tiles;
-  }
-  // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
-  // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
-  // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
-  const int tiles_m = tiles / tiles_n;
-  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
-  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  int Cin = p.C0 + p.C1;
-  int NCm = Cin >> 6;
-  const int NC = NCm + ((p.X0 + p.X1) >> 6);
-  int c_begin = kz * p.ksteps_per;                         // chunks, not K-steps, for this kernel
-  int c_end = min(c_begin + p.ksteps_per, NC);
-  const bool gn = p.gn_partial != nullptr;
-  const bool silu = p.gn_silu != 0;
-
-  const int W = p.Wo, Hh = p.Ho;
-  int W2 = W + 2;
-  int TH = BM / W;
-  const int img = m0 / (Hh * W);
-  int y0 = (m0 - img * Hh * W) / W;
-  int Hi = p.Hs << p.ups;                                  // == Hh (and the width == W)
-  const int rowp = W >> 3;                                 // 8-pixel pieces per image row (power of two: launcher)
-  int lrp = 31 - __builtin_clz(rowp);
-  int NHI = (TH + 2) * rowp;                               // pieces per halo (<= MAXP * NW: launcher)
-  int hbytes = halo_bytes;
-  PIN_S(Cin); PIN_S(NCm); PIN_S(c_begin); PIN_S(c_end); PIN_S(W2); PIN_S(TH); PIN_S(y0); PIN_S(Hi); PIN_S(lrp); PIN_S(NHI);
-  PIN_S(hbytes);
-
-  char* const hbase = smem;
-  char* const bring = smem + 3 * hbytes;
-  float* const tab = (float*)(bring + NS * C::B_BYTES);    // [2][64][2]: (a, b) per channel of a chunk
-  double* const s_red = (double*)(tab + 256);              // [8][32][2]
-  float* const s_mean = (float*)(s_red + 512);             // [32], s_rstd = s_mean + 32
-  char* const dump = (char*)(s_mean + 64);
-  (void)dump;
-  auto hbuf = [&](int c) { return hbase + ((c - c_begin) % 3) * hbytes; };
-  auto ntap = [&](int c) { return c < NCm ? 9 : 1; };
-
-  const int r = lane & 31, h = lane >> 5;
-
-  // in-place normalisation of piece q of a landed raw halo (prologue form: indices computed on the fly)
-  auto transform_piece_q = [&](int q, int c, char* hb) {
-    if (q >= NHI) return;
-    const int hy = q >> lrp, seg = q & (rowp - 1);
-    if ((unsigned)(y0 - 1 + hy) >= (unsigned)Hi) return;            // out-of-image row: zeros stay zeros (wave-uniform)
-    const int hp = hy * W2 + 1 + seg * 8 + (lane >> 3);
-    const int slot = lane & 7, gch = slot ^ ((hp >> 1) & 7);
-    f16x8* px = (f16x8*)(hb + hp * 128 + slot * 16);
-    const f32x4* ab = (const f32x4*)(tab + (c & 1) * 128 + gch * 16);
-    *px = gn_apply8(*px, ab[0], ab[1], ab[2], ab[3], silu);
-  };
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (role == 1) {
-    // ================================ DMA waves ================================
-    // halo pieces owned by this wave: piece q = j*NW + wave, 8 consecutive interior pixels of one halo row
-    int h_pix[MAXD], h_gch[MAXD], h_lds[MAXD];
-    unsigned in_mask = 0;                                  // bit j: this lane's pixel of piece j lies inside the image
-    unsigned edge_mask = 0, have_mask = 0;                 // wave-uniform: piece j in halo row 0 / TH+1; piece j exists
-#pragma unroll
-    for (int j = 0; j < MAXD; ++j) {
-      const int q = j * ND + wave;
-      const int hy = q >> lrp, seg = q & (rowp - 1);
-      const int hx = 1 + seg * 8 + (lane >> 3);
-      const int hp = hy * W2 + hx;
-      const int y = y0 - 1 + hy, x = hx - 1;
-      if (q < NHI) have_mask |= 1u << j;
-      if (hy == 0 || hy == TH + 1) edge_mask |= 1u << j;
-      if (q < NHI && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)(p.Ws << p.ups)) in_mask |= 1u << j;
-      h_pix[j] = img * p.Hs * p.Ws + (y >> p.ups) * p.Ws + (x >> p.ups);
-      h_gch[j] = ((lane & 7) ^ ((hp >> 1) & 7)) * 8;
-      h_lds[j] = (hy * W2 + 1 + seg * 8) * 128;
-    }
-    const f16* zero = p.zero;
-    // per-chunk source descriptor of the halo being staged (set once per chunk)
-    const f16* sbase = zero;
-    int sld = 0;
-    unsigned smask = 0;                                    // pieces of that chunk to stage
-    auto open_source = [&](int c) {
-      const bool extra = c >= NCm;
-      const int cabs = (extra ? c - NCm : c) << 6;
-      const int Ca = extra ? p.X0 : p.C0;
-      const bool second = cabs >= Ca;
-      const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
-      sld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
-      sbase = base + (second ? cabs - Ca : cabs);
-      smask = extra ? (have_mask & ~edge_mask) : have_mask;   // the skip conv reads the centre tap only
-    };
-    auto halo_piece = [&](int j, char* hb) -> int {
-      if (!((smask >> j) & 1)) return 0;
-      const f16* g = ((in_mask >> j) & 1) ? sbase + ((size_t)h_pix[j] * sld + h_gch[j]) : zero + h_gch[j];
-      glds16(g, hb + h_lds[j]);
-      return 1;
-    };
-    // weight tile rows of this lane
-    const f16* b_base[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int q = (i * ND + wave) * 64 + lane;
-      const int row = q >> 3, pc = q & 7;
-      const int gch = (pc ^ ((row >> 1) & 7)) * 8;
-      const int n = n0 + row;
-      b_base[i] = n < p.N ? p.w + (size_t)n * p.ldw + gch : zero;
-    }
-    bool b_ok[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) b_ok[i] = n0 + (((i * ND + wave) * 64 + lane) >> 3) < p.N;
-    int sc = c_begin, stap = 0;                            // (chunk, tap) of the next weight tile to stage
-    auto stage_b = [&](int slot) {
-      const int koff = sc < NCm ? stap * Cin + (sc << 6) : 9 * Cin + ((sc - NCm) << 6);
-      char* sb = bring + slot * C::B_BYTES;
-#pragma unroll
-      for (int i = 0; i < RB; ++i) glds16(b_ok[i] ? b_base[i] + koff : zero, sb + (i * ND + wave) * 1024);
-      if (++stap == ntap(sc)) { stap = 0; ++sc; }
-    };
-    int nk = 0;
-    for (int c = c_begin; c < c_end; ++c) nk += ntap(c);
-
-    // prologue: raw halos of the first two chunks + the first NS-1 weight tiles
-    open_source(c_begin);
-#pragma unroll
-    for (int j = 0; j < MAXD; ++j) (void)halo_piece(j, hbuf(c_begin));
-    if (c_begin + 1 < c_end) {
-      open_source(c_begin + 1);
-#pragma unroll
-      for (int j = 0; j < MAXD; ++j) (void)halo_piece(j, hbuf(c_begin + 1));
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < NS - 1; ++s2)
-      if (s2 < nk) stage_b(s2);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                          // A: halos landed, padding columns zeroed, s_red written
-    if (gn) {
-      __builtin_amdgcn_s_barrier();                        // B: s_mean / s_rstd
-      __builtin_amdgcn_s_barrier();                        // C: tables of the first two chunks
-      if (c_begin < NCm)
-        for (int q = wave_id; q < NHI; q += NALL) transform_piece_q(q, c_begin, hbuf(c_begin));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // D: halo(c_begin) normalised
-    }
-    int nxt = NS - 1, t = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-      const int nt = ntap(c);
-      const bool stage_h = c + 2 < c_end;
-      char* const hb2 = hbuf(c + 2);
-      if (stage_h) open_source(c + 2);
-      for (int tau = 0; tau < nt; ++tau, ++t) {
-        int n_issued = 0;
-        if (t + NS - 1 < nk) { stage_b(nxt); n_issued += RB; }
-        if (stage_h) {
-#pragma unroll
-          for (int j = 0; j < MAXD; ++j)
-            if (nt == 1 || j == tau) n_issued += halo_piece(j, hb2);
-        }
-        wait_vmcnt_dyn(n_issued);
-        __builtin_amdgcn_s_barrier();
-        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      }
-    }
-  } else if (role == 2) {
-    // ================================ X waves: normalise halo(c+1) while chunk c is multiplied ================================
-    int t_off[MAXP], t_tab[MAXP];
-    unsigned do_mask = 0;                                  // wave-uniform: piece j exists and its row is inside the image
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int q = j * NW + wave;
-      const int hy = q >> lrp, seg = q & (rowp - 1);
-      const int hp = hy * W2 + 1 + seg * 8 + (lane >> 3);
-      const int slot = lane & 7, gch = slot ^ ((hp >> 1) & 7);
-      if (q < NHI && (unsigned)(y0 - 1 + hy) < (unsigned)Hi) do_mask |= 1u << j;
-      t_off[j] = hp * 128 + slot * 16;
-      t_tab[j] = gch * 16;
-    }
-    const float* gamma = p.gn_gamma;
-    const float* beta = p.gn_beta;
-    const int cpg = (p.C0 + p.C1) >> 5;
-    float gam_n = 0.f, bet_n = 0.f;
-    __builtin_amdgcn_s_barrier();                          // A
-    if (gn) {
-      __builtin_amdgcn_s_barrier();                        // B
-      __builtin_amdgcn_s_barrier();                        // C
-      if (c_begin < NCm)
-        for (int q = wave_id; q < NHI; q += NALL) transform_piece_q(q, c_begin, hbuf(c_begin));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // D
-    }
-    for (int c = c_begin; c < c_end; ++c) {
-      const int nt = ntap(c);
-      const bool xform = gn && c + 1 < c_end && c + 1 < NCm;
-      char* const hb1 = hbuf(c + 1);
-      const float* const tb = tab + ((c + 1) & 1) * 128;
-      // software pipeline: the LDS reads of piece j are issued in interval j and consumed in interval j + 1, so their
-      // latency rides across the barrier instead of sitting in front of it.  Piece j of halo(c+1) was DMA'd at interval j
-      // of chunk c-1 (or in the prologue): its DMA wave retired it with a counted wait a whole chunk of barriers ago.
-      f16x8 pv = {};
-      f32x4 pa0 = {}, pa1 = {}, pa2 = {}, pa3 = {};
-      f16x8* ppx = nullptr;
-      // X wave 0 also builds the (a, b) table of chunk c+2 (slot c & 1: last read while halo(c) was normalised, during
-      // chunk c-1): gamma / beta are loaded at the first interval of chunk c and used at its last one
-      const bool tab_next = gn && wave == 0 && c + 2 < c_end && c + 2 < NCm;
-      for (int tau = 0; tau < nt; ++tau) {
-        if (tab_next && tau == 0) { gam_n = gamma[((c + 2) << 6) + lane]; bet_n = beta[((c + 2) << 6) + lane]; }
-        if (tab_next && tau == nt - 1) {
-          const int ch = ((c + 2) << 6) + lane;
-          const int g = ch / cpg;
-          const float a = s_mean[32 + g] * gam_n;
-          *(f32x2*)(tab + (c & 1) * 128 + lane * 2) = f32x2{a, bet_n - s_mean[g] * a};
-        }
-        if (xform) {
-          if (ppx) { *ppx = gn_apply8(pv, pa0, pa1, pa2, pa3, silu); ppx = nullptr; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the write has retired before this interval's barrier
-#pragma unroll
-          for (int j = 0; j < MAXP; ++j)
-            if (j == tau && ((do_mask >> j) & 1)) {
-              ppx = (f16x8*)(hb1 + t_off[j]);
-              const f32x4* ab = (const f32x4*)(tb + t_tab[j]);
-              pv = *ppx; pa0 = ab[0]; pa1 = ab[1]; pa2 = ab[2]; pa3 = ab[3];
-            }
-        }
-        if (tab_next && tau == nt - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-  } else {
-    // ================================ MFMA waves ================================
-    // zero the padding columns of the three halo buffers once
-    for (int i = tid; i < (TH + 2) * 2 * 8 * 3; i += NW * 64) {        // (row, side, 16-B chunk, buffer)
-      const int ch = i & 7, side = (i >> 3) & 1, rest = i >> 4;
-      const int buf = rest % 3, hy = rest / 3;
-      const int hp = hy * W2 + (side ? W + 1 : 0);
-      f16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
-      *(f16x8*)(hbase + buf * hbytes + hp * 128 + ch * 16) = z;
-    }
-    const int cpg = (p.C0 + p.C1) >> 5;
-    if (gn && tid < 256) {
-      // statistics of this tile's image: same slicing and summation order as gn_apply_kernel
-      const int g = tid & 31, sl = tid >> 5;
-      double s = 0.0, q = 0.0;
-      f32x2 pv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int ch = sl + 8 * k;
-        pv[k] = ch < p.gn_nchunk ? *(const f32x2*)(p.gn_partial + (((size_t)img * p.gn_nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { s += (double)pv[k][0]; q += (double)pv[k][1]; }
-      s_red[(sl * 32 + g) * 2] = s;
-      s_red[(sl * 32 + g) * 2 + 1] = q;
-    }
-    // gamma / beta of the first two chunks: issued now so that their latency overlaps the halo DMA wait (barrier A)
-    const float* gamma = p.gn_gamma;
-    const float* beta = p.gn_beta;
-    float g0 = 0.f, be0 = 0.f, g1 = 0.f, be1 = 0.f;
-    if (gn && wave == 0) {
-      if (c_begin < NCm) { g0 = gamma[(c_begin << 6) + lane]; be0 = beta[(c_begin << 6) + lane]; }
-      if (c_begin + 1 < c_end && c_begin + 1 < NCm) { g1 = gamma[((c_begin + 1) << 6) + lane]; be1 = beta[((c_begin + 1) << 6) + lane]; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // A
-    // (a, b) of chunk c into table slot c & 1 from gamma / beta values this lane holds
-    auto write_tab = [&](int c, float gam, float bet) {
-      const int ch = (c << 6) + lane;
-      const int g = ch / cpg;
-      const float a = s_mean[32 + g] * gam;
-      *(f32x2*)(tab + (c & 1) * 128 + lane * 2) = f32x2{a, bet - s_mean[g] * a};
-    };
-    if (gn) {
-      if (tid < 32) {
-        double s = 0.0, q = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) { s += s_red[(sl * 32 + tid) * 2]; q += s_red[(sl * 32 + tid) * 2 + 1]; }
-        const double cnt = (double)cpg * (double)(p.Hs * p.Ws);
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        s_mean[tid] = (float)mean;
-        s_mean[32 + tid] = rsqrtf((float)var + p.gn_eps);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // B
-      if (wave == 0) {
-        if (c_begin < NCm) write_tab(c_begin, g0, be0);
-        if (c_begin + 1 < c_end && c_begin + 1 < NCm) write_tab(c_begin + 1, g1, be1);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // C
-      if (c_begin < NCm)
-        for (int q = wave_id; q < NHI; q += NALL) transform_piece_q(q, c_begin, hbuf(c_begin));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // D
-    }
-    int base_hp[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int rr = wm * C::TM + i * 32 + r;
-      const int ty = rr / W, tx = rr - ty * W;
-      base_hp[i] = ty * W2 + tx;
-    }
-    const int bkey = (r >> 1) & 7;
-    const int b_row_off = (wn * C::TN + r) * 128;
-    const int bco = (h ^ bkey) << 4;
-    int cur = 0;
-    __builtin_amdgcn_s_setprio(1);                         // the matrix waves go first; the X waves' VALU fills the gaps
-    for (int c = c_begin; c < c_end; ++c) {
-      const int nt = ntap(c);
-      const char* hb = hbuf(c);
-      for (int tau = 0; tau < nt; ++tau) {
-        const int tp = nt == 9 ? tau : 4;
-        const int kh = tp / 3, kw = tp - kh * 3;
-        const char* Bs = bring + cur * C::B_BYTES + b_row_off;
-        int a_off[FM], a_co[FM];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int hp = base_hp[i] + kh * W2 + kw;
-          a_off[i] = hp * 128;
-          a_co[i] = (h ^ ((hp >> 1) & 7)) << 4;
-        }
-        f16x8 af[2][FM], bf[2][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(hb + a_off[i] + a_co[i]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[0][j] = *(const f16x8*)(Bs + j * 32 * 128 + bco);
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          if (s2 < 3) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) af[(s2 + 1) & 1][i] = *(const f16x8*)(hb + a_off[i] + (a_co[i] ^ ((s2 + 1) << 5)));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bf[(s2 + 1) & 1][j] = *(const f16x8*)(Bs + j * 32 * 128 + (bco ^ ((s2 + 1) << 5)));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s2 & 1][i], bf[s2 & 1][j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  }
-
-  float* Cs = (float*)smem;
-  if (role == 0)
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int col = wn * C::TN + j * 32 + r;
-          Cs[row * BN + col] = acc[i][j][e];
-        }
-  __syncthreads();
-  store_tile<BM, BN, NT>(p, Cs, m0, n0, kz, tid);
-}
-
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
@@ -1587,30 +1134,17 @@ const CfgInfo kHaloCfgs[] = {
     CFG_ENTRY_H(128, 160, 4, 1, 3),
 };
 constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
-// fused GroupNorm(+SiLU) halo convs (conv3_gn_kernel): the only configs that accept GemmArgs::gn_partial
-#define CFG_ENTRY_G(BM, BN, WM, WN) \
-  {"g" #BM "x" #BN, BM, BN, 3, GCfg<BM, BN, WM, WN>::NT, GCfg<BM, BN, WM, WN>::TAIL, nullptr, conv3_gn_kernel<GCfg<BM, BN, WM, WN>>, \
-   GCfg<BM, BN, WM, WN>::MAXP, GCfg<BM, BN, WM, WN>::NW}
-#define CFG_ENTRY_G2(BM, BN, WM, WN) \
-  {"g" #BM "x" #BN "d2", BM, BN, 3, GCfg<BM, BN, WM, WN, 2>::NT, GCfg<BM, BN, WM, WN, 2>::TAIL, nullptr, conv3_gn_kernel<GCfg<BM, BN, WM, WN, 2>>, \
-   GCfg<BM, BN, WM, WN, 2>::MAXP, GCfg<BM, BN, WM, WN, 2>::NW}
-const CfgInfo kGnCfgs[] = {
-    CFG_ENTRY_G(128, 128, 2, 2), CFG_ENTRY_G(128, 64, 2, 2), CFG_ENTRY_G(64, 128, 2, 2), CFG_ENTRY_G(64, 64, 2, 2),
-    CFG_ENTRY_G2(128, 128, 2, 2), CFG_ENTRY_G2(128, 64, 2, 2),
-};
-constexpr int kNumGn = sizeof(kGnCfgs) / sizeof(kGnCfgs[0]);
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kMaxDev = 16;
-bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo + kNumGn] = {};   // hipFuncSetAttribute is per device
+bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo] = {};   // hipFuncSetAttribute is per device
 
 }  // namespace
 
 static const CfgInfo& cfg_info(int cfg) {
   if (cfg < kNumCfgs) return kCfgs[cfg];
-  if (cfg < kNumCfgs + kNumHalo) return kHaloCfgs[cfg - kNumCfgs];
-  return kGnCfgs[cfg - kNumCfgs - kNumHalo];
+  return kHaloCfgs[cfg - kNumCfgs];
 }
-int sdmi_gemm_num_cfgs() { return kNumCfgs + kNumHalo + kNumGn; }
+int sdmi_gemm_num_cfgs() { return kNumCfgs + kNumHalo; }
 const char* sdmi_gemm_cfg_name(int cfg) {
   if (cfg >= 0 && cfg < sdmi_gemm_num_cfgs()) return cfg_info(cfg).name;
   return "?";
@@ -1633,33 +1167,9 @@ static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
   return true;
 }
 
-static int gn_halo_bytes(const GemmArgs& a, const CfgInfo& c) {
-  const int TH = c.BM / a.Wo;
-  return (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
-}
-static int gn_lds_bytes(const GemmArgs& a, const CfgInfo& c) {
-  const int lds = 3 * gn_halo_bytes(a, c) + c.NS * c.BN * 128 + c.LDS /* = TAIL */;
-  return lds < c.BM * c.BN * 4 ? c.BM * c.BN * 4 : lds;
-}
-// conv3_gn_kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image, power-of-two width
-static bool gn_ok(const GemmArgs& a, const CfgInfo& c) {
-  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.rowstat || a.ln_stat || a.outT || a.act) return false;
-  if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
-  if (a.Wo < 8 || (a.Wo & (a.Wo - 1)) != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
-  const int TH = c.BM / a.Wo;
-  if ((TH + 2) * (a.Wo / 8) > c.ntaph /* = MAXP */ * c.nw) return false;
-  if (gn_lds_bytes(a, c) > 160 * 1024) return false;
-  if (a.gn_partial) {
-    if (a.ups != 0 || a.gn_nchunk < 1 || a.gn_nchunk > 128 || !a.gn_gamma || !a.gn_beta || (a.C0 + a.C1) % 32 != 0) return false;
-  }
-  return true;
-}
-
 bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= sdmi_gemm_num_cfgs()) return false;
   const CfgInfo& c = cfg_info(cfg);
-  if (cfg >= kNumCfgs + kNumHalo) return gn_ok(a, c);
-  if (a.gn_partial) return false;               // only the fused kernel normalises the A operand
   if (c.BN % 64 != 0 && (a.ks != 3 || a.rowstat || a.ln_stat || a.outT)) return false;   // 160-wide tiles: 3x3 convs only
   if (a.outT && (a.nt0 % c.BN) != 0) return false;
   if (a.act == 2 && (c.BN != 128 || cfg >= kNumCfgs)) return false;                      // softmax epilogue: one head per n-tile
@@ -1686,7 +1196,7 @@ size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int /*cfg*/, int ksplit) {
   return ksplit > 1 ? (size_t)ksplit * a.M * a.N * sizeof(float) : 0;
 }
 
-int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out) {
+int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out, int* ksteps_per_out) {
   SDMI_REQUIRE(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
   SDMI_REQUIRE(a.N % 8 == 0 && a.N > 0, "gemm: N=%d must be a positive multiple of 8", a.N);
   SDMI_REQUIRE(a.M > 0, "gemm: M=%d", a.M);
@@ -1707,27 +1217,16 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
                "gemm: a phase-decomposed x2-upsample conv needs ks = 2, M = 4*B*Hs*Ws, img_rows = M/4 and a plain epilogue");
   SDMI_REQUIRE(a.zero && a.a0 && a.w && a.out, "gemm: null pointer");
   SDMI_REQUIRE(a.ldc % 8 == 0 && (!a.res || a.ldr % 8 == 0), "gemm: ldc/ldr must be multiples of 8");
-  if (cfg < 0) {
-    cfg = pick_cfg(a);
-    if (a.gn_partial) {                          // heuristic for the fused path: the first applicable g-config
-      cfg = -1;
-      for (int g = kNumCfgs + kNumHalo; g < sdmi_gemm_num_cfgs() && cfg < 0; ++g)
-        if (gn_ok(a, cfg_info(g))) cfg = g;
-      SDMI_REQUIRE(cfg >= 0, "gemm: no fused GroupNorm config fits this conv (Wo=%d)", a.Wo);
-    }
-  }
+  if (cfg < 0) cfg = pick_cfg(a);
   SDMI_REQUIRE(cfg < sdmi_gemm_num_cfgs(), "gemm: bad cfg %d", cfg);
-  const bool gnk = cfg >= kNumCfgs + kNumHalo;
-  const bool halo = cfg >= kNumCfgs && !gnk;
+  const bool halo = cfg >= kNumCfgs;
   const CfgInfo& c = cfg_info(cfg);
   if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
   SDMI_REQUIRE(c.BN % 64 == 0 || (a.ks == 3 && !a.rowstat && !a.ln_stat && !a.outT), "gemm: config %s (160-wide tile) is not applicable to this GEMM: 3x3 convs only", c.name);
-  if (gnk) SDMI_REQUIRE(gn_ok(a, c), "gemm: fused-GroupNorm config %s not applicable to this conv", c.name);
-  SDMI_REQUIRE(gnk || !a.gn_partial, "gemm: config %s cannot normalise its A operand", c.name);
-  SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && !gnk && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
+  SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
                               a.sm_valid > 0 && a.sm_valid <= 128),
                "gemm: the softmax epilogue needs a BN=128 plain tile, full tiles (M %% BM == 0, N %% 128 == 0), fp16 output, no split-K / residual");
-  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && !gnk && (a.ks == 1 || a.phase2) && (a.ksplit <= 1 || a.phase2)),
+  SDMI_REQUIRE(a.img_rows == 0 || (a.img_rows % c.BM == 0 && a.M % a.img_rows == 0 && !halo && (a.ks == 1 || a.phase2) && (a.ksplit <= 1 || a.phase2)),
                "gemm: per-image weights need BM | img_rows | M, a 1x1 GEMM and no split-K");
   if (a.outT) {
     SDMI_REQUIRE(a.nt0 % c.BN == 0, "gemm: transposed tail start %d not a multiple of BN=%d", a.nt0, c.BN);
@@ -1752,12 +1251,6 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
   if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
   p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
-  if (gnk) {                                            // this kernel splits in CHUNKS (64 input channels x 9 taps, or a skip chunk)
-    const int NC = (a.C0 + a.C1 + a.X0 + a.X1) / 64;
-    int ks = a.ksplit < 1 ? 1 : (a.ksplit > NC ? NC : a.ksplit);
-    p.ksteps_per = (NC + ks - 1) / ks;
-    p.ksplit = (NC + p.ksteps_per - 1) / p.ksteps_per;
-  }
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
   const int tiles = ((a.M + c.BM - 1) / c.BM) * ((a.N + c.BN - 1) / c.BN);
   int dev = 0;
@@ -1771,11 +1264,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     }
     return SDMI_OK;
   };
-  if (gnk) {
-    if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
-    hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), gn_lds_bytes(a, c), st, p, gn_halo_bytes(a, c));
-    SDMI_CHECK_HIP(hipGetLastError());
-  } else if (halo) {
+  if (halo) {
     const int TH = c.BM / a.Wo;
     const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
     int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
@@ -1790,6 +1279,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     SDMI_CHECK_HIP(hipGetLastError());
   }
   if (ksplit_out) *ksplit_out = p.ksplit;
+  if (ksteps_per_out) *ksteps_per_out = p.ksteps_per;
   if (p.ksplit > 1 && !p.no_finalize) {
     const size_t total8 = (size_t)p.M * (p.N / 8);
     int blocks = (int)((total8 + 255) / 256);

@@ -418,7 +418,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   return SDMI_OK;
 }
 
-// statistics only: partial {sum, sum of squares} per (image, pixel chunk, group) for the fused conv (conv3_gn_kernel)
+// statistics only: partial {sum, sum of squares} per (image, pixel chunk, group) (consumer: the back-to-back kernel, SDMI_B2B_GN)
 int sdmi_launch_gn_stats(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
   SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "gn_stats: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);

@@ -232,6 +232,46 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   return SDMI_OK;
 }
 
+// A second LANE over the same packed weights: its own activation arena, split-K slabs, context buffers, time vectors and
+// plans, so two denoising loops (two prompts) can run concurrently on two streams of one GPU and fill each other's
+// per-launch latency (a single chain leaves ~20 % of the chip idle: profiles/r02_bench_2rank_rehearsal.json).  The clone
+// borrows every weight pointer of `src`; `src` must outlive it.
+int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out) {
+  if (!src || !out) { sdmi_set_error("sdmi_unet_clone: null argument"); return SDMI_EINVAL; }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != src->device) {
+    sdmi_set_error("sdmi_unet_clone: the source handle lives on HIP device %d but device %d is current", src->device, cur);
+    return SDMI_EINVAL;
+  }
+  sdmi_unet* u = new sdmi_unet();
+  u->flags = src->flags; u->stream_f32 = src->stream_f32; u->partial = src->partial; u->tune = src->tune;
+  u->weight_bytes = 0;                                   // borrowed
+  u->res = src->res; u->attn = src->attn; u->convs = src->convs;
+  u->te1 = src->te1; u->te2 = src->te2; u->has_time = src->has_time; u->time_total = src->time_total;
+  u->res_order = src->res_order; u->attn_order = src->attn_order;
+  u->stem_w36 = src->stem_w36; u->stem_bias = src->stem_bias; u->stem_cout = src->stem_cout; u->has_stem = src->has_stem;
+  u->final_gn = src->final_gn; u->final_conv = src->final_conv; u->has_final = src->has_final;
+  u->plans = src->plans;
+  for (auto& kv : u->plans) { kv.second.calls = 0; }
+  auto fail = [&](int rc) { delete u; return rc; };
+  int rc;
+  if ((rc = u->dmalloc(&u->zero, 4096)) != SDMI_OK) return fail(rc);
+  if (hipMemset(u->zero, 0, 4096) != hipSuccess) return fail(SDMI_EHIP);
+  if (hipMemsetD16((hipDeviceptr_t)(u->zero + 1024), 0x3C00, 1024) != hipSuccess) return fail(SDMI_EHIP);
+  u->max_steps = src->max_steps;
+  if ((rc = u->dmalloc(&u->time_scratch, (size_t)2 * u->max_steps * kTime * 4)) != SDMI_OK) return fail(rc);
+  if ((rc = u->dmalloc(&u->timevec, (size_t)u->max_steps * (u->time_total ? u->time_total : 1) * 4)) != SDMI_OK) return fail(rc);
+  if ((rc = u->dmalloc(&u->timevec_adhoc, (size_t)(u->time_total ? u->time_total : 1) * 4)) != SDMI_OK) return fail(rc);
+  u->slab_bytes = src->slab_bytes;
+  if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
+  if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
+  u->arena.cap = src->arena.cap;
+  if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
+  if (hipDeviceSynchronize() != hipSuccess) return fail(SDMI_EHIP);
+  *out = u;
+  return SDMI_OK;
+}
+
 void sdmi_unet_destroy(sdmi_unet* u) {
   if (u) { (void)hipDeviceSynchronize(); u->plan_report("unet"); delete u; }
 }
@@ -418,7 +458,7 @@ int sdmi_unet_profile(sdmi_unet* u, int enable) {
 
 int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_class, int* launches_by_class) {
   if (!u || !ms_by_class || !flops_by_class || !launches_by_class) { sdmi_set_error("profile_read: null argument"); return SDMI_EINVAL; }
-  for (int c = 0; c < 3; ++c) { ms_by_class[c] = 0; flops_by_class[c] = 0; launches_by_class[c] = 0; }
+  for (int c = 0; c < 4; ++c) { ms_by_class[c] = 0; flops_by_class[c] = 0; launches_by_class[c] = 0; }
   for (auto& r : u->prof) {
     SDMI_CHECK_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;
@@ -465,8 +505,6 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.outT = (f16*)d->out_t; a.nt0 = d->nt0; a.S = d->S; a.ldt = d->ldt; a.tperm = d->out_t_perm;
   a.x0 = (const f16*)d->x0; a.x1 = (const f16*)d->x1; a.X0 = d->cx0; a.X1 = d->cx1;
   a.rowstat = d->rowstat; a.ln_stat = d->ln_stat; a.ln_ntn = d->ln_ntn; a.ln_g = d->ln_g; a.ln_C = d->ln_c; a.ln_eps = d->ln_eps;
-  a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta;
-  a.gn_eps = d->gn_eps; a.gn_silu = d->gn_silu;
   a.act = d->act; a.sm_valid = d->sm_valid; a.img_rows = d->img_rows; a.w_img_stride = d->w_img_stride;
   a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw; a.phase2 = d->phase2;
   a.ln_ksteps = d->ln_ksteps; a.ln_out = d->ln_out;

@@ -59,10 +59,29 @@ class Diffusion:
         return iter(self._state.values())
 
     def _drop_handle(self):
+        for ln in getattr(self, "_lanes", []):
+            ln._drop_handle()
+        self._lanes = []
         if self._handle is not None:
             self._handle.close()
         self._handle = None
         self._ctx_key = None
+
+    def lane(self) -> "Diffusion":
+        """A second LANE of this model: same weights (the packed copies on the GPU are shared, nothing is re-packed), own
+        activation arena / context / schedule.  Two lanes driven on two HIP streams run two independent generate() loops
+        concurrently on one GPU and fill each other's per-launch latency (``replicas.run_prompts(streams_per_gpu=2)``).
+        The lane is dropped with this model's handle."""
+        ln = Diffusion.__new__(Diffusion)
+        ln._manifest, ln._state, ln._device = self._manifest, self._state, self._device
+        ln.stream_f32, ln.autotune = self.stream_f32, self.autotune
+        ln._ctx_key = None
+        ln._lanes = []
+        ln._handle = self.handle().clone()
+        if not hasattr(self, "_lanes"):
+            self._lanes = []
+        self._lanes.append(ln)
+        return ln
 
     # ---- native handle -----------------------------------------------------------------------------
     def handle(self):
@@ -79,9 +98,24 @@ class Diffusion:
         return self._handle
 
     def set_context(self, context: torch.Tensor):
-        """Hoist the cross-attention K/V projections of ``context`` (B,77,768).  Always recomputed:
-        a pointer/version cache would be unsafe (the caching allocator reuses addresses)."""
+        """Hoist the cross-attention K/V projections of ``context`` (B,77,768) and build the folded cross-attention operands
+        (32 GEMMs + 66 fold launches, ~0.6 ms).  Unconditional; ``__call__`` skips it when the context did not change."""
         self.handle().set_context(context.to(self._device, torch.float32))
+        self._ctx_key = None
+
+    def _context_signature(self, ctx32: torch.Tensor):
+        """Content signature of a context tensor, computed ON the GPU (two fp64 reductions, one of them against a fixed
+        pseudo-random weight vector; one 16-byte read-back): a pointer / version cache would be unsafe (the caching allocator
+        reuses addresses), hashing on the host would copy 0.5 MB per call."""
+        n = ctx32.numel()
+        w = getattr(self, "_sig_w", None)
+        if w is None or w.numel() != n or w.device != ctx32.device:
+            g = torch.Generator(device="cpu").manual_seed(0x5D31)
+            w = torch.rand(n, generator=g, dtype=torch.float64).to(ctx32.device)
+            self._sig_w = w
+        flat = ctx32.reshape(-1).double()
+        sig = torch.stack([flat.sum(), (flat * w).sum()]).tolist()
+        return (tuple(ctx32.shape), sig[0], sig[1])
 
     def set_schedule(self, time_embeddings: torch.Tensor):
         """time_embeddings: (n_steps, 320) rows of get_time_embedding(t)."""
@@ -110,8 +144,14 @@ class Diffusion:
     # ---- reference call convention -------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, latent: torch.Tensor, context: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
-        """latent (B,4,h,w), context (B,77,768), time (1,320) -> (B,4,h,w)   (sd/diffusion.py:797)."""
-        self.set_context(context)
+        """latent (B,4,h,w), context (B,77,768), time (1,320) -> (B,4,h,w)   (sd/diffusion.py:797).  The reference's own
+        loop passes the same context on every step (sd/pipeline.py:225): the per-prompt hoist is redone only when its
+        content changed (INTEGRATION.md mode 1: the object swapped in under the reference's loop)."""
+        ctx32 = context.to(self._device, torch.float32)
+        sig = self._context_signature(ctx32)
+        if sig != self._ctx_key:
+            self.handle().set_context(ctx32)
+            self._ctx_key = sig
         lat = latent.to(self._device, torch.float32)
         temb = time.to(self._device, torch.float32).reshape(1, 320)
         return self.handle().forward(lat, lat.shape[0], temb=temb)

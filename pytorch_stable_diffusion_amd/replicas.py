@@ -146,12 +146,55 @@ def gather_image_lists(mine: List[torch.Tensor], n_total: int, shape, device=Non
     return out if rank == dst else None
 
 
+class _Serialised:
+    """A model shared by several lanes of one GPU (CLIP, the VAE): one caller at a time, and the caller's stream has drained
+    before the next one may reuse the handle's activation arena."""
+
+    def __init__(self, inner, lock):
+        self._inner, self._lock = inner, lock
+
+    def to(self, device):
+        with self._lock:
+            self._inner.to(device)
+        return self
+
+    def __call__(self, *args, **kw):
+        with self._lock:
+            out = self._inner(*args, **kw)
+            if torch.is_tensor(out) and out.is_cuda:
+                torch.cuda.current_stream(out.device).synchronize()
+            return out
+
+
+def lane_models(models: Dict[str, object], n_lanes: int) -> List[Dict[str, object]]:
+    """``n_lanes`` model dicts for concurrent generate() loops on ONE GPU: every lane shares the CLIP / VAE objects of
+    ``models`` (serialised: one caller at a time); lane 0 drives ``models["diffusion"]`` itself, the others their own lane of
+    it (``Diffusion.lane()``: shared packed weights, own scratch)."""
+    import threading
+    if n_lanes <= 1:
+        return [models]
+    lock = threading.Lock()
+    shared = {k: _Serialised(v, lock) for k, v in models.items() if k != "diffusion"}
+    out = []
+    for i in range(n_lanes):
+        d = dict(shared)
+        unet = models["diffusion"]
+        d["diffusion"] = unet if i == 0 or not hasattr(unet, "lane") else unet.lane()
+        out.append(d)
+    return out
+
+
 def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, device, *, seed_base: int = 0,
                 uncond_prompt: str = "", n_inference_steps: int = 50, cfg_scale: float = 7.5, height: int = 512,
                 width: int = 512, input_images: Optional[Sequence] = None, strength: float = 0.8, group=None,
-                gather_device=None, generate=None):
+                gather_device=None, generate=None, streams_per_gpu: int = 1):
     """Shard ``prompts`` over the ranks of the initialised process group (prompt i -> rank i mod N, seed =
-    seed_base + i), run generate() per prompt, gather on rank 0.  Returns (images or None, stats)."""
+    seed_base + i), run generate() per prompt, gather on rank 0.  Returns (images or None, stats).
+
+    ``streams_per_gpu`` > 1: throughput mode -- this rank's prompts are dealt to that many LANES, each a thread running
+    generate() on its own HIP stream over the shared packed weights (``lane_models``).  Every image is the same as in the
+    one-lane run (same seed, same kernels, same plans); only the wall time per BATCH of prompts changes."""
+    import threading
     import time
 
     import torch.distributed as dist
@@ -160,28 +203,60 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     todo = shard_prompts(list(enumerate(prompts)), rank, world)
-    mine: List[torch.Tensor] = []
-    per_image = []
+    on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
+    n_lanes = max(1, min(int(streams_per_gpu), len(todo))) if todo else 1
+    lanes = lane_models(models, n_lanes)
+    results: Dict[int, torch.Tensor] = {}
+    per_image: Dict[int, float] = {}
+    errors: List[BaseException] = []
+
+    def work(lane: int):
+        stream = torch.cuda.Stream(device=device) if (on_gpu and n_lanes > 1) else None
+        try:
+            for i, prompt in todo[lane::n_lanes]:
+                t1 = time.perf_counter()
+                ctx = torch.cuda.stream(stream) if stream is not None else _null_ctx()
+                with ctx:
+                    img = generate(prompt=prompt, uncond_prompt=uncond_prompt,
+                                   input_image=None if input_images is None else input_images[i], strength=strength,
+                                   do_cfg=True, cfg_scale=cfg_scale, sampler_name="ddpm", n_inference_steps=n_inference_steps,
+                                   models=lanes[lane], seed=seed_base + i, device=device, idle_device=None,
+                                   tokenizer=tokenizer, height=height, width=width)
+                results[i] = torch.from_numpy(img)
+                per_image[i] = time.perf_counter() - t1
+        except BaseException as exc:      # re-raised on the caller's thread
+            errors.append(exc)
+
     if dist.is_initialized():
         dist.barrier(group)
     t0 = time.perf_counter()
-    for i, prompt in todo:
-        t1 = time.perf_counter()
-        img = generate(prompt=prompt, uncond_prompt=uncond_prompt,
-                       input_image=None if input_images is None else input_images[i], strength=strength, do_cfg=True,
-                       cfg_scale=cfg_scale, sampler_name="ddpm", n_inference_steps=n_inference_steps, models=models,
-                       seed=seed_base + i, device=device, idle_device=None, tokenizer=tokenizer, height=height,
-                       width=width)
-        mine.append(torch.from_numpy(img))
-        per_image.append(time.perf_counter() - t1)
-    if torch.cuda.is_available() and torch.device(device).type == "cuda":
+    if n_lanes == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(k,), name=f"sdmi-lane-{k}") for k in range(n_lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    if on_gpu:
         torch.cuda.synchronize(device)
+    mine = [results[i] for i, _ in todo]
     elapsed = max_over_ranks(time.perf_counter() - t0, device=gather_device, group=group)
     images = gather_image_lists(mine, len(prompts), (height, width, 3), device=gather_device, group=group)
-    stats = {"n_prompts": len(prompts), "world": world, "elapsed_s": elapsed,
+    stats = {"n_prompts": len(prompts), "world": world, "streams_per_gpu": n_lanes, "elapsed_s": elapsed,
              "images_per_s": len(prompts) / elapsed if elapsed > 0 else 0.0,
-             "rank0_s_per_image": per_image}
+             "rank0_s_per_image": [per_image[i] for i, _ in todo]}
     return images, stats
+
+
+class _null_ctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def _main(argv=None) -> int:
@@ -203,6 +278,8 @@ def _main(argv=None) -> int:
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--out-dir", default=None)
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="throughput mode: this many concurrent generate() lanes per GPU over one copy of the packed weights")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs")
     args = ap.parse_args(argv)
     if bool(args.ckpt) == bool(args.synthetic):
@@ -248,7 +325,8 @@ def _main(argv=None) -> int:
     models = model_loader.preload_models_from_state_dicts(state, dev)
 
     images, stats = run_prompts(prompts, models, tokenizer, dev, seed_base=args.seed_base, n_inference_steps=args.steps,
-                                cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=dev)
+                                cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=dev,
+                                streams_per_gpu=args.streams_per_gpu)
     if rank == 0:
         if args.out_dir:
             from PIL import Image

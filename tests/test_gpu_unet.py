@@ -219,3 +219,46 @@ def test_plan_cache_makes_second_process_deterministic_and_tune_free(tmp_path):
     assert runs[1][1] == runs[2][1], runs
     files = [f for f in os.listdir(tmp_path) if f.startswith("plans-")]
     assert len(files) == 1
+
+
+def test_call_rehoists_context_only_when_it_changed(full_model):
+    """Diffusion.__call__ (the reference's model(latent, context, time) surface, sd/pipeline.py:225) keeps the per-prompt
+    hoist of an unchanged context and redoes it for a new one -- also when the new tensor reuses the old one's storage."""
+    from oracle import ddpm_ref
+    lat = H.seeded((1, 4, 16, 16), 7).repeat(2, 1, 1, 1).to(DEV)
+    temb = ddpm_ref.time_embedding(500).to(DEV)
+    c1 = H.seeded((2, 77, 768), 31).to(DEV)
+    c2 = H.seeded((2, 77, 768), 32)
+    a = full_model(lat, c1, temb)
+    key = full_model._ctx_key
+    b = full_model(lat, c1.clone(), temb)                     # same content, other storage: no re-hoist, same result
+    assert full_model._ctx_key == key and torch.equal(a, b)
+    c1.copy_(c2.to(DEV))                                      # new content in the OLD storage
+    c = full_model(lat, c1, temb)
+    assert full_model._ctx_key != key and not torch.equal(a, c)
+    full_model.set_context(c2.to(DEV))                        # explicit hoist: the same numbers
+    d = full_model.handle().forward(lat, 2, temb=temb)
+    assert torch.equal(c, d)
+
+
+def test_second_lane_matches_first(full_model):
+    """Diffusion.lane(): a second set of scratch buffers over the SAME packed weights (sdmi_unet_clone) gives bit-identical
+    results, also while the first lane runs on another stream."""
+    from oracle import ddpm_ref
+    lane = full_model.lane()
+    ctx = H.seeded((2, 77, 768), 1).to(DEV)
+    temb = ddpm_ref.time_embedding(980).to(DEV)
+    lat = H.seeded((1, 4, 32, 32), 9).repeat(2, 1, 1, 1).to(DEV)
+    want = full_model(lat, ctx, temb)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            o1 = full_model(lat, ctx, temb)
+        with torch.cuda.stream(s2):
+            o2 = lane(lat, ctx, temb)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, want) and torch.equal(o2, want)

@@ -161,3 +161,32 @@ def test_generate_level_launcher_world2_matches_single_process():
     assert len(got) == 5
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == (64, 64, 3) and (g == w).all(), f"prompt {i}"
+
+
+def test_streams_per_gpu_lanes_keep_prompt_order_and_images():
+    """run_prompts(streams_per_gpu=2): the rank's prompts are dealt to two lanes (threads); the images come back in prompt
+    order and equal the one-lane run (CPU stub models: the lane plumbing, no GPU)."""
+    from tests.stub_tokenizer import StubTokenizer
+    models = _stub_models(_stub_weights())
+    one, s1 = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64,
+                                   width=64, generate=_stub_generate)
+    two, s2 = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64,
+                                   width=64, generate=_stub_generate, streams_per_gpu=2)
+    assert s1["streams_per_gpu"] == 1 and s2["streams_per_gpu"] == 2
+    assert len(one) == len(two) == len(_PROMPTS)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    lanes = replicas.lane_models(models, 3)
+    assert len(lanes) == 3 and lanes[0]["diffusion"] is models["diffusion"]
+    assert all(isinstance(l["clip"], replicas._Serialised) and isinstance(l["decoder"], replicas._Serialised) for l in lanes)
+    assert replicas.lane_models(models, 1) == [models]
+
+
+def test_lane_error_is_raised_on_the_caller():
+    from tests.stub_tokenizer import StubTokenizer
+
+    def boom(**kw):
+        raise ValueError("lane failure")
+
+    with pytest.raises(ValueError, match="lane failure"):
+        replicas.run_prompts(_PROMPTS, _stub_models(_stub_weights()), StubTokenizer(), "cpu", generate=boom, streams_per_gpu=2)

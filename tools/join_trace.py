@@ -80,6 +80,18 @@ def shape_key(kind, kv):
     return kind
 
 
+def family_of(kind):
+    if kind in ("igemm", "halo", "b2b"):
+        return "mfma"
+    if kind == "finalize":
+        return "finalize"
+    if kind in ("attn", "xattn"):
+        return "attn"
+    if kind.startswith(("gn", "layer")):
+        return "norm"
+    return "other"
+
+
 def cmd_time(trace, logp, which=None):
     rows = read_rows(trace)
     steps = steps_of(rows)
@@ -95,6 +107,14 @@ def cmd_time(trace, logp, which=None):
         a[3] += float(kv.get("wbytes", 0))
     tot = sum(a[1] for a in agg.values())
     print(f"{len(step)} kernels in the step, {sum(a[0] for a in agg.values())} matched, {tot:.1f} us")
+    fams = collections.OrderedDict()
+    for (kind, kv, _), r in align(step, log):
+        f = fams.setdefault(family_of(kind), [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        f[2] += float(kv.get("flops", 0))
+    for f, (n, us, fl) in fams.items():
+        print(f"  family {f:9s} x{n:3d} {us:8.1f} us" + (f"  {fl / us * 1e-6:7.1f} TF/s" if fl else ""))
     for k, (n, us, fl, wb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         extra = f"  {fl / us * 1e-6:7.1f} TF/s  {wb / us * 1e-3:7.1f} GB/s weights" if fl else ""
         print(f"  {k:78s} x{n:3d} {us:8.1f} us  avg {us / n:7.2f}{extra}")
@@ -126,7 +146,9 @@ def cmd_pmc(fetch_csv, write_csv, logp, outp):
                         e["algorithmic"] += (N * K * 2 + a_in + out_b) / len(steps)
     fam = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
     for k, e in res.items():
-        f = "igemm" if e["kind"] in ("igemm", "halo", "finalize", "b2b") else ("attn" if e["kind"] in ("attn", "xattn") else ("norm" if e["kind"].startswith(("gn", "layer")) else "other"))
+        # ONE family definition, shared with bench.py and cmd_mfma: "mfma" = the GEMM kernels that run MFMAs (implicit-GEMM conv /
+        # linear, halo conv, back-to-back GEMM); "finalize" = the combine launches of split-K GEMMs, reported on their own
+        f = family_of(e["kind"])
         fam[f][0] += e["FETCH_SIZE"]; fam[f][1] += e["WRITE_SIZE"]; fam[f][2] += e["launches_per_step"]
         e["hbm_bytes"] = e["FETCH_SIZE"] + e["WRITE_SIZE"]
         e["launches_per_step"] = round(e["launches_per_step"], 2)
@@ -135,6 +157,7 @@ def cmd_pmc(fetch_csv, write_csv, logp, outp):
                    "'algorithmic' = weights once + input activations once + outputs (and residual) once, per GEMM shape.",
            "steps_averaged": nsteps, "launch_log_entries": len(log),
            "families": {f: {"fetch_bytes": v[0], "write_bytes": v[1], "hbm_bytes": v[0] + v[1], "launches": round(v[2])} for f, v in fam.items()},
+           "whole_step": {"hbm_bytes": sum(v[0] + v[1] for v in fam.values()), "launches": round(sum(v[2] for v in fam.values()))},
            "by_shape": collections.OrderedDict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes"]))}
     json.dump(out, open(outp, "w"), indent=1)
     print(json.dumps(out["families"], indent=1))
@@ -153,7 +176,7 @@ def cmd_mfma(csv_path, logp, outp):
         steps = steps_of(rows)[-8:]
         for step in steps:
             for (kind, kv, _), r in align(step, log):
-                fam = "igemm" if kind in ("igemm", "halo", "b2b") else kind
+                fam = family_of(kind)
                 e = per.setdefault(fam, collections.defaultdict(float))
                 e[counter] += float(r["Counter_Value"]) / len(steps)
                 if counter == "SQ_VALU_MFMA_BUSY_CYCLES":
