@@ -368,7 +368,13 @@ int launch(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
   } else {
     dim3 grid((a.Sq + 127) / 128, a.B * a.H);
-    hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), C::LDS + C::EXTRA, st, a);
+    // diagnostic knob (A/B only): extra dynamic LDS per workgroup caps the workgroups per CU, i.e. the waves per SIMD
+    static const int lds_pad = getenv("SDMI_ATTN_LDS_PAD") ? atoi(getenv("SDMI_ATTN_LDS_PAD")) : 0;
+    if (lds_pad > 0) {
+      static bool pad_attr = false;
+      if (!pad_attr) { SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); pad_attr = true; }
+    }
+    hipLaunchKernelGGL((attn_kernel<D, false>), grid, dim3(256), C::LDS + C::EXTRA + lds_pad, st, a);
   }
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;

@@ -13,7 +13,9 @@ loaded with the name-keyed synthetic weights and the stub tokenizer.
 Per run: uint8 image, 4x-subsampled float image (decoder output, [-1,1]), final latents, the latents entering every
 5th UNet call (drift localisation) and {mean, std} of the latents entering every step.
 
-usage: make_golden_e2e50.py [txt50] [img50] [t768]      (default: all three; existing keys of e2e50.npz are kept)
+  config 5 at its stated step count: txt2img 768x768, 50 steps, seed 1                 -> t768x50_* (e2e768.npz; ~15 min of CPU)
+
+usage: make_golden_e2e50.py [txt50] [img50] [t768] [t768x50]      (default: the first three; existing keys are kept)
 """
 import os
 import sys
@@ -127,6 +129,25 @@ def main():
         del out["t768_lat_every5"]
         out["t768_u8"] = img[::2, ::2]                   # 384x384x3 subsample keeps the fixture small
         save()
+    if "t768x50" in which:
+        saved = {k: getattr(ref_pipeline, k) for k in ("WIDTH", "HEIGHT", "LATENTS_WIDTH", "LATENTS_HEIGHT")}
+        ref_pipeline.WIDTH = ref_pipeline.HEIGHT = 768
+        ref_pipeline.LATENTS_WIDTH = ref_pipeline.LATENTS_HEIGHT = 96
+        try:
+            t0 = time.time()
+            img = ref_pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True,
+                                        cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=50, models=mods, seed=1,
+                                        device="cpu", idle_device=None, tokenizer=tok)
+            print(f"txt2img 768x768, 50 steps: {time.time()-t0:.1f}s", flush=True)
+        finally:
+            for k, v in saved.items():
+                setattr(ref_pipeline, k, v)
+        lat_in = torch.cat(unet.inputs)
+        np.savez_compressed(os.path.join(HERE, "e2e768.npz"), t768x50_u8=img[::2, ::2],       # 384x384x3 subsample
+                            t768x50_float=dec.last[0, :, ::8, ::8].numpy(), t768x50_latents=dec.last_in.numpy(),
+                            t768x50_lat_stats=torch.stack([lat_in.mean(dim=(1, 2, 3)), lat_in.std(dim=(1, 2, 3))], 1).numpy(),
+                            threads=np.array(torch.get_num_threads()))
+        unet.inputs.clear()
     print({k: getattr(v, "shape", None) for k, v in out.items()})
 
 

@@ -151,6 +151,26 @@ def test_768_generate_matches_reference(models):
     assert du8.max() <= U8_MAX, f"768x768: uint8 max diff {du8.max()}"
 
 
+def test_768_generate_50_steps_matches_reference(models):
+    """BASELINE config 5 at its stated step count: txt2img 768x768, 50 DDPM steps, CFG 7.5, seed 1, against the reference's
+    own generate() (tests/golden/e2e768.npz, make_golden_e2e50.py t768x50).  Skipped when the fixture is absent."""
+    import os
+    from pytorch_stable_diffusion_amd import pipeline
+    path = os.path.join(H.GOLDEN, "e2e768.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/e2e768.npz not generated")
+    g = np.load(path)
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", do_cfg=True, cfg_scale=7.5, n_inference_steps=50,
+                            models=models, seed=1, device=DEV, tokenizer=StubTokenizer(), height=768, width=768)
+    got_f = models["decoder"].last[0, :, ::8, ::8].cpu()
+    ref_f = torch.from_numpy(g["t768x50_float"])
+    mae = ((got_f - ref_f).abs().mean() / 2.0).item()
+    du8 = np.abs(img[::2, ::2].astype(np.int32) - g["t768x50_u8"].astype(np.int32))
+    G.log_metric(test="e2e", name="t768x50", pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()))
+    assert mae < PIXEL_MAE, f"768x768, 50 steps: pixel MAE {mae:.2e}"
+    assert du8.max() <= U8_MAX, f"768x768, 50 steps: uint8 max diff {du8.max()}"
+
+
 def test_native_vae_decoder_vs_reference():
     """Native HIP VAE decoder (csrc/vae.hip) vs the reference decoder's golden outputs at 8x8 latents and at 64x64
     latents (the size generate() uses; image kept 4x subsampled), incl. quirks Q3/Q4."""

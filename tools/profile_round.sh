@@ -1,19 +1,38 @@
 #!/bin/bash
-# Final-form profiles of one round: rocprofv3 kernel stats + per-step summary + HBM traffic (separate PMC passes).
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r01z
+# One-call profiling recipe of a round on the GPU box (run through gpurun from the repo root):  tools/profile_round.sh r03
+#   kernel trace + launch log -> per-shape times; separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy | MFMA ops)
+# Counter passes carry only --kernel-trace besides --pmc (gpurun refuses other trace domains with counters).
 set -e
-TAG=${1:-r01z}
-ROOT=$PWD
-OUT=$ROOT/gpurun_out/$TAG
-mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py --steps 30 --warmup 10 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 10 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/fetch.log
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 10 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/write.log
-cd $ROOT
-python3 tools/trace_step.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_kernel_summary.txt
-cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
-python3 tools/pmc_traffic.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_hbm_traffic.json > /dev/null
-tail -1 $OUT/bench_under_rocprof.json > $OUT/${TAG}_bench_under_rocprof.json
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/bench_under_rocprof.json
-head -12 $OUT/${TAG}_step_kernel_summary.txt
+tag=${1:-r03}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+export SDMI_LAUNCH_LOG=$PWD/$out/launch_log.txt
+B="python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/bench_trace.json 2> $out/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B > /dev/null 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B > /dev/null 2> $out/write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/mfma -o m -- $B > /dev/null 2> $out/mfma.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/mops -o o -- $B > /dev/null 2> $out/mops.err
+find $out -name "*.csv" | head -20
+python3 tools/join_trace.py time $(find $out/trace -name "*kernel_trace.csv") $out/launch_log.txt > $out/step_by_shape.txt
+python3 tools/join_trace.py pmc $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/launch_log.txt $out/hbm_traffic_by_shape.json > $out/pmc_summary.txt
+python3 tools/join_trace.py mfma $(find $out/mfma -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_busy.json > $out/mfma_summary.txt
+python3 tools/join_trace.py mfma $(find $out/mops -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_ops.json > $out/mops_summary.txt
+cp $(find $out/trace -name "*kernel_stats.csv") $out/kernel_stats.csv
+python3 - "$out" <<'PY'
+import json, sys
+out = sys.argv[1]
+b = json.loads(open(f"{out}/bench_trace.json").read().strip().splitlines()[-1])
+n = b["config"]["launches_per_step"]
+for f in ("hbm_traffic_by_shape.json", "mfma_busy.json", "mfma_ops.json"):
+    j = json.load(open(f"{out}/{f}"))
+    j["bench_launches_per_step"] = n
+    j["bench_command"] = "python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency (under rocprofv3 --pmc ...)"
+    j["family_definition"] = "mfma = igemm_kernel + conv3_halo_kernel + b2b_kernel; finalize = splitk_finalize; attn; norm = GroupNorm / LayerNorm kernels; other"
+    json.dump(j, open(f"{out}/{f}", "w"), indent=1)
+print("launches/step", n)
+PY
+# the raw CSVs are large: keep only the summaries (the merge back is capped at 64 MiB)
+rm -rf $out/trace $out/fetch $out/write $out/mfma $out/mops
+ls -la $out
