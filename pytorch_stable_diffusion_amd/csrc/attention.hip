@@ -22,6 +22,13 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Diagnostic builds (tools/build_variant.sh ... -DSDMI_ATTN_ABLATE=<bits>): drop one component of the tile loop to read its cost
+// off the kernel time (results are then wrong): 1 exp2 -> move, 2 three quarters of the PV MFMAs + V reads, 4 two thirds of the
+// QK^T MFMAs + K reads, 8 no K/V staging after the first tile, 16 no per-tile wait + barrier (use with 8)
+#ifndef SDMI_ATTN_ABLATE
+#define SDMI_ATTN_ABLATE 0
+#endif
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -51,9 +58,12 @@ struct ACfg {
   static constexpr int EXTRA = SPARE ? 16 : 0;     // the K-side bias fragment behind the stages
 };
 
-template <int D, bool SPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+// NW = waves per workgroup: 4, or 8 for the key-split form over 128 queries (long sequences: four waves per SIMD at the
+// same K/V bytes staged per query as the unsplit form)
+template <int D, bool SPLIT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs p) {
   typedef ACfg<D> C;
+  static_assert(NW == 4 || (SPLIT && NW == 8), "8-wave workgroups only in the key-split form");
   constexpr int NSUB = SPLIT ? 2 : 1;                 // key streams staged per step (SPLIT: one tile of each half)
   constexpr int STAGE2 = NSUB * C::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,14 +72,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const int r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / p.H, head = bh % p.H;
   const int hk = SPLIT ? (wave & 1) : 0;              // which half of the keys this wave reduces
-  const int q0 = SPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+  const int q0 = SPLIT ? blockIdx.x * (NW * 16) + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
   const int ntiles = SPLIT ? (p.Skv >> 7) : (p.Skv + 63) >> 6;   // tiles per stream (SPLIT: Skv % 128 == 0, launcher)
 
   const f16* kbase = p.k + (size_t)b * p.k_batch_stride * p.ldk + head * D;
   const f16* vbase = p.vt + ((size_t)(b * p.H + head) * D) * p.ldvt;
 
   // per-lane LDS-DMA source pointers, advanced by one 64-key tile per stage() call
-  constexpr int KI = (C::K_INST + 3) / 4, VI = C::V_INST / 4;
+  constexpr int KI = (C::K_INST + NW - 1) / NW, VI = (C::V_INST + NW - 1) / NW;
   const f16* kptr[NSUB][KI];
   int krow[KI];
   const f16* vptr[NSUB][VI];
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   const int half_keys = ntiles * 64;                   // SPLIT: first key of the second stream
 #pragma unroll
   for (int i = 0; i < KI; ++i) {
-    const int q = (i * 4 + wave) * 64 + lane;
+    const int q = (i * NW + wave) * 64 + lane;
     const int row = q / C::KCH, c = q - row * C::KCH;
     krow[i] = row;
 #pragma unroll
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < VI; ++i) {
-    const int q = (i * 4 + wave) * 64 + lane;
+    const int q = (i * NW + wave) * 64 + lane;
     const int row = q >> 3, pc = q & 7;
     const int gch = pc ^ ((row >> 1) & 7);
     // row D of the padded V^T tile is all ones: the PV MFMA then also produces the row sums of P (the softmax
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       char* sv = sk + C::K_BYTES;
 #pragma unroll
       for (int i = 0; i < KI; ++i) {
-        const int ii = i * 4 + wave;
+        const int ii = i * NW + wave;
         if (ii < C::K_INST) {
           const f16* g = (SPLIT || stage_key0 + krow[i] < p.Skv) ? kptr[u][i] : p.zero;
           glds16(g, sk + ii * 1024);
@@ -114,8 +124,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < VI; ++i) {
-        glds16(vptr[u][i], sv + (i * 4 + wave) * 1024);
-        vptr[u][i] += vinc[i];
+        if (C::V_INST % NW == 0 || i * NW + wave < C::V_INST) {
+          glds16(vptr[u][i], sv + (i * NW + wave) * 1024);
+          vptr[u][i] += vinc[i];
+        }
       }
     }
     stage_key0 += 64;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) {
+      for (int s = 0; s < ((SDMI_ATTN_ABLATE & 4) ? 1 : C::NS); ++s) {
         const char* ka = Ks + (kb * 32 + r) * (D * 2) + koff[s];
         if (C::SPARE && s == C::NS - 1) ka = h == 1 ? kbias_lds : ka;       // padding columns of K: {1, 0, ...} against Q's {-m_run, 0, ...}
         const f16x8 kf = *(const f16x8*)ka;
@@ -250,8 +262,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float p0 = __builtin_amdgcn_exp2f(sacc[0][e]);
-      const float p1 = __builtin_amdgcn_exp2f(sacc[1][e]);
+      const float p0 = (SDMI_ATTN_ABLATE & 1) ? sacc[0][e] : __builtin_amdgcn_exp2f(sacc[0][e]);
+      const float p1 = (SDMI_ATTN_ABLATE & 1) ? sacc[1][e] : __builtin_amdgcn_exp2f(sacc[1][e]);
       sacc[0][e] = p0;
       sacc[1][e] = p1;
       if constexpr (!C::LROW) { ps0 += p0; ps1 += p1; }
@@ -267,6 +279,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         // keys of this k16 step held by half h: quads h and 2+h of 16-key group 2*kb + s2 -- adjacent in the
         // permuted V^T storage (gemm.hip vt_pos): one 16-byte read at chunk 2*group + h
         const int o0 = (((4 * kb + 2 * s2 + h) ^ vkey) << 4);
+        if ((SDMI_ATTN_ABLATE & 2) && (kb | s2)) { asm volatile("" ::"v"(pf)); continue; }
 #pragma unroll
         for (int d = 0; d < C::DB; ++d) {
           const f16x8 vf = *(const f16x8*)(Vs + (d * 32 + r) * 128 + o0);
@@ -284,9 +297,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   // bodies in one loop the register allocator copied all of O^T every tile): tile 0, unmasked tiles, masked tail.
   int cur = 0;
   auto step = [&](int t, auto masked_tag, auto first_tag) {
-    if (t + 1 < ntiles) stage(cur ^ 1);
+    if (!(SDMI_ATTN_ABLATE & 8) && t + 1 < ntiles) stage(cur ^ 1);
     tile_body(masked_tag, first_tag, t, cur);
-    if (t + 1 < ntiles) {
+    if (!(SDMI_ATTN_ABLATE & 16) && t + 1 < ntiles) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -357,13 +370,23 @@ int launch(const AttnArgs& a, hipStream_t st) {
   if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + C::EXTRA));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS + C::EXTRA));
+    if constexpr (D == 40)
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS + C::EXTRA));
     attr_done[dev] = true;
   }
   // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
   static const bool split_on = !(getenv("SDMI_ATTN_SPLIT") && atoi(getenv("SDMI_ATTN_SPLIT")) == 0);
   // (at S = 4096 the split form stages four times the K/V bytes per query and loses: attention 0.646 vs 0.617 ms/step)
   static const int split_max = getenv("SDMI_ATTN_SPLIT_MAXS") ? atoi(getenv("SDMI_ATTN_SPLIT_MAXS")) : 1024;
-  if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS + C::EXTRA <= 160 * 1024) {
+  // long sequences (d = 40, S = 4096): 128-query workgroups of EIGHT waves, the wave pairs again splitting the keys: the K/V
+  // bytes staged per query equal the unsplit form's, and four waves per SIMD hide each other's dependent tile chains
+  static const int split8_min = getenv("SDMI_ATTN_SPLIT8_MINS") ? atoi(getenv("SDMI_ATTN_SPLIT8_MINS")) : 2048;
+  if (D == 40 && split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 128 == 0 && a.Sq >= split8_min) {
+    if constexpr (D == 40) {
+      dim3 grid(a.Sq / 128, a.B * a.H);
+      hipLaunchKernelGGL((attn_kernel<D, true, 8>), grid, dim3(512), 2 * C::LDS + C::EXTRA, st, a);
+    }
+  } else if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS + C::EXTRA <= 160 * 1024) {
     dim3 grid(a.Sq / 64, a.B * a.H);
     hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
   } else {
