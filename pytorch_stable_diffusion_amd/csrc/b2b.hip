@@ -63,6 +63,7 @@ __device__ unsigned long long g_b2b_clk[2][8];   // diagnostic build: shader-clo
 
 template <class Cf>
 __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
+  sdmi_kernarg_warm<sizeof(B2bArgs)>();
   constexpr int kBM = Cf::kBM, kMW = Cf::kMW, kNR = Cf::kNR, kAStage = Cf::kAStage, kCsBytes = Cf::kCsBytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -13,6 +13,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef __HIPCC__
+// Kernel arguments are read with s_load next to their first use, each behind its own s_waitcnt: with a 100-360 byte argument
+// struct that is a dozen SERIAL scalar-cache misses (~300 cycles each: the launch's kernarg slot is new memory) before the
+// first tile is requested -- 1.6 us of the 3.8 k-cycle set-up measured on the K = C GEMMs (tools/phase_probe.py).  Touching
+// every 64-byte line of the struct at the top of the kernel turns them into ONE miss latency; the later loads hit.
+template <int BYTES>
+__device__ __forceinline__ void sdmi_kernarg_warm() {
+#ifdef SDMI_NO_KERNARG_WARM      // A/B builds
+  return;
+#endif
+  typedef const __attribute__((address_space(4))) int* kptr_t;
+  kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int L = (BYTES + 63) / 64;
+  int t[L + 1];
+#pragma unroll
+  for (int i = 0; i < L; ++i) t[i] = ka[i * 16];
+  t[L] = ka[(BYTES - 4) / 4];            // the segment is only guaranteed 16-byte aligned: the last argument may sit in one more line
+                                         // (never read past BYTES: a kernel without hidden arguments ends there)
+#pragma unroll
+  for (int i = 0; i <= L; ++i) asm volatile("" ::"s"(t[i]));
+}
+#endif
+
 #define SDMI_OK 0
 #define SDMI_EINVAL (-22)
 #define SDMI_ENOMEM (-12)

@@ -20,24 +20,29 @@
 
 namespace {
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0, int KPI_ = 1>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0, int KPI_ = 1, int PW_ = 1>
 struct Cfg {
   static constexpr int KPI = KPI_;   // K-steps (of 64) per barrier interval (wave-specialised ring only)
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;   // NS = LDS ring depth
   static constexpr int STG = STG_;   // 0: every wave stages and computes; 2: producer/consumer wave specialisation
   // NW = waves that own MFMA sub-tiles (and, for STG 0/1, also stage).  STG 2 adds NW producer waves that
   // only issue LDS-DMA, so each SIMD holds one MFMA wave and one DMA wave.
-  static constexpr int NW = WM * WN, NT = 64 * NW * (STG_ == 2 ? 2 : 1);
+  // PW (STG 2 only): producer waves per MFMA wave.  One wave issues ~4.6 B/clk of LDS-DMA whatever its queue depth
+  // (profiles/r03_load_paths.txt), so the K-loop of a small tile with NW producers runs at their issue rate, not at the
+  // matrix pipe's; SW = staging waves.
+  static constexpr int NW = WM * WN, SW = (STG_ == 2 ? NW * PW_ : NW), NT = 64 * (NW + (STG_ == 2 ? SW : 0));
+  static_assert(STG_ == 2 || PW_ == 1, "producer multiplier needs the wave-specialised ring");
   static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int RA = BM * 8 / (64 * NW), RB = BN * 8 / (64 * NW);
+  static constexpr int RA = BM * 8 / (64 * SW), RB = BN * 8 / (64 * SW);
   static constexpr int CS_BYTES = BM * BN * 4;
   static constexpr int RING = NS * KPI * STAGE;
   static constexpr int LDS = (RING > CS_BYTES) ? RING : CS_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(NS >= 2 && NS <= 8, "ring depth");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32x32");
-  static_assert((BM * 8) % (64 * NW) == 0 && (BN * 8) % (64 * NW) == 0, "staging must divide evenly");
+  static_assert((BM * 8) % (64 * SW) == 0 && (BN * 8) % (64 * SW) == 0, "staging must divide evenly");
+  static_assert(NT <= 1024, "workgroup size");
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -283,6 +288,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
 
 #ifdef SDMI_CLK_PROBE
 __device__ unsigned long long g_clk_probe[2048][2];   // diagnostic build only: {shader cycles, 100 MHz ticks} per workgroup
+__device__ unsigned long long g_clk_pre[2048][10];     // igemm STG 2: producer {setup done, NS-1 stages issued, first stage landed}, consumer {first barrier passed}
 __device__ unsigned long long g_clk_phase[2048][6];   // {realtime start, end, cycles after setup / K loop / tile in LDS / end}
 #endif
 
@@ -291,7 +297,16 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT;
+  sdmi_kernarg_warm<sizeof(GemmArgs) + 16>();     // + the hidden grid size this kernel reads (gridDim.x)
+  // every argument the prologue needs, requested in ONE batch: left to itself the compiler loads each next to its first use behind
+  // its own wait, and even scalar-cache hits then cost ~100 cycles apiece in series
+  asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
+               "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
+               "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.X0), "s"(p.X1));
+#ifdef SDMI_CLK_PROBE
+  if (threadIdx.x == 0 && blockIdx.x < 2048) g_clk_pre[blockIdx.x][4] = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
+  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT, SW = C::SW;
   constexpr int FM = C::FM, FN = C::FN, RA = C::RA, RB = C::RB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -299,7 +314,8 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
   // wave-uniform roles (STG 2): waves [0,NW) run ds_read + MFMA, waves [NW,2NW) only issue LDS-DMA
   const bool producer = C::STG == 2 && wave_id >= NW;
-  const int wave = wave_id % NW;                              // index inside its role group
+  const int wave = producer ? 0 : wave_id;                    // MFMA wave index (producers own no sub-tile)
+  const int sw = C::STG == 2 ? (producer ? wave_id - NW : 0) : wave_id;   // index among the staging waves
   const int wm = wave / C::WN, wn = wave % C::WN;
   // XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
   // b+8 share an L2), so a plain map makes every XCD stream the whole activation tensor through its
@@ -313,20 +329,25 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, loc = bid >> 3;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    kz = L / tiles;
-    tile = L - kz * tiles;
+    if (p.ksplit == 1) { kz = 0; tile = L; }
+    else { kz = L / tiles; tile = L - kz * tiles; }
   }
   // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
   // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
   // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
-  const int tiles_m = tiles / tiles_n;
-  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
-  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tdiv = p.n_major ? tiles_m : tiles_n;      // ONE scalar division (~30 instructions, ~300 cycles each on a lone wave)
+  const int tq = tile / tdiv, tr = tile - tq * tdiv;
+  const int tm = p.n_major ? tr : tq;
+  const int tn = p.n_major ? tq : tr;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = p.K >> 6;
   const int kt0 = kz * p.ksteps_per;
   const int kt1 = min(kt0 + p.ksteps_per, nkt);
 
+#ifdef SDMI_CLK_PROBE
+  if (C::STG == 2 && threadIdx.x == 64 * C::NW && blockIdx.x < 2048) g_clk_pre[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   // LayerNorm fold: mean / rstd of this tile's rows from the producer's per-n-tile partial sums.  Issued first so
   // the loads overlap the main loop; read after the epilogue barrier.
   __shared__ float s_ln[2 * BM + BN];       // {mean, rstd} per tile row, then ln_g of the tile's columns (ln_ksteps > 0)
@@ -355,6 +376,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     }
   }
 
+#ifdef SDMI_CLK_PROBE
+  if (C::STG == 2 && threadIdx.x == 64 * C::NW && blockIdx.x < 2048) g_clk_pre[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   const int Cin = p.C0 + p.C1;
   const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
 
@@ -366,18 +390,24 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   bool a_ok[RA];
   const f16* a_ptr[RA];
   int a_inc[RA];
+  const bool plain = p.ks == 1 && p.stride == 1 && p.ups == 0 && p.C1 == 0 && p.X0 == 0 && p.X1 == 0 && p.phase2 == 0;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int q = (i * NW + wave) * 64 + lane;
+    const int q = (i * SW + sw) * 64 + lane;
     const int row = q >> 3, pc = q & 7;
     a_gch[i] = (pc ^ ((row >> 1) & 7)) * 8;          // element offset of the global chunk to fetch
     const int m = m0 + row;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
-    if (p.ks == 1 && p.stride == 1 && p.ups == 0) {
-      // plain GEMM (every linear / 1x1 conv: 130 of the 178 launches of a step): output row m IS source pixel m, so
-      // the four integer divisions per staged row (~35 VALU instructions each) of the im2col decomposition are skipped
+    if (plain) {
+      // plain GEMM (every linear / 1x1 conv over one source: 122 of the launches of a step): output row m IS source row m and K is
+      // ONE segment, so neither the im2col decomposition (four integer divisions per staged row) nor the segment walk exists --
+      // the prologue of these launches was ~2 k cycles of address arithmetic before the first tile was requested
+      a_ptr[i] = a_ok[i] ? p.a0 + ((size_t)mm * p.lda0 + (size_t)kt0 * 64 + a_gch[i]) : p.zero + a_gch[i];
+      a_inc[i] = a_ok[i] ? 64 : 0;
       a_ihb[i] = 0; a_iwb[i] = 0; a_pix0[i] = mm;
+    } else if (p.ks == 1 && p.stride == 1 && p.ups == 0) {
+      a_ihb[i] = 0; a_iwb[i] = 0; a_pix0[i] = mm;      // 1x1 over a virtual concat: row m is source pixel m of both sources
     } else if (p.phase2) {
       const int rp = p.M >> 2;
       const int ph = mm / rp, rem = mm - ph * rp;
@@ -394,11 +424,14 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       a_pix0[i] = b * p.Hs * p.Ws;
     }
   }
+#ifdef SDMI_CLK_PROBE
+  if (C::STG == 2 && threadIdx.x == 64 * C::NW && blockIdx.x < 2048) g_clk_pre[blockIdx.x][7] = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   const f16* b_ptr[RB];
   int b_inc[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int q = (i * NW + wave) * 64 + lane;
+    const int q = (i * SW + sw) * 64 + lane;
     const int row = q >> 3, pc = q & 7;
     const int gch = (pc ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
@@ -407,11 +440,18 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     b_inc[i] = ok ? 64 : 0;
   }
 
+#ifdef SDMI_CLK_PROBE
+  if (C::STG == 2 && threadIdx.x == 64 * C::NW && blockIdx.x < 2048) g_clk_pre[blockIdx.x][8] = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
   // segment state (wave-uniform)
-  int tap = (kt0 * 64) / Cin;
-  int seg_c = kt0 * 64 - tap * Cin;       // channel offset inside the concatenated Cin
-  if (tap >= p.ks * p.ks) { tap = p.ks * p.ks; seg_c = kt0 * 64 - tap * Cin; }   // inside the extra 1x1 segment
+  int tap = 0, seg_c = 0;
   int seg_left = 0;                       // K-steps left in the current segment
+  if (plain) seg_left = 1 << 30;          // one segment, opened above
+  else {
+    tap = (kt0 * 64) / Cin;
+    seg_c = kt0 * 64 - tap * Cin;         // channel offset inside the concatenated Cin
+    if (tap >= p.ks * p.ks) { tap = p.ks * p.ks; seg_c = kt0 * 64 - tap * Cin; }   // inside the extra 1x1 segment
+  }
 
   const int ntaps = p.ks * p.ks;
   auto open_segment = [&]() {
@@ -445,12 +485,12 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     if (seg_left == 0) open_segment();
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      glds16(a_ptr[i], sa + (i * NW + wave) * 1024);
+      glds16(a_ptr[i], sa + (i * SW + sw) * 1024);
       a_ptr[i] += a_inc[i];
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      glds16(b_ptr[i], sb + (i * NW + wave) * 1024);
+      glds16(b_ptr[i], sb + (i * SW + sw) * 1024);
       b_ptr[i] += b_inc[i];
     }
     --seg_left;
@@ -536,15 +576,26 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
           if (it * KPI + j < nk) stage(slot * KPI + j);
           else if (KPI > 1) {            // keep the per-interval DMA count constant for counted vmcnt
 #pragma unroll
-            for (int i = 0; i < RA + RB; ++i) glds16(p.zero, smem + ((slot * KPI + j) * C::STAGE) + (i * NW + wave) * 1024);
+            for (int i = 0; i < RA + RB; ++i) glds16(p.zero, smem + ((slot * KPI + j) * C::STAGE) + (i * SW + sw) * 1024);
           }
       };
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long pre0 = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s)
         if (s < ni) stage_interval(s, s);
+#ifdef SDMI_CLK_PROBE
+      const unsigned long long pre1 = __builtin_amdgcn_s_memtime() - clk_t0;
+#endif
       {
         wait_ring<NS - 2, G>(ni - 1);
       }
+#ifdef SDMI_CLK_PROBE
+      if (lane == 0 && sw == 0 && blockIdx.x < 2048) {
+        g_clk_pre[blockIdx.x][0] = pre0; g_clk_pre[blockIdx.x][1] = pre1; g_clk_pre[blockIdx.x][2] = __builtin_amdgcn_s_memtime() - clk_t0;
+      }
+#endif
       __builtin_amdgcn_s_barrier();
       int nxt = NS - 1;
 #ifdef SDMI_CLK_PROBE
@@ -580,6 +631,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
       int cur = 0;
 #ifdef SDMI_CLK_PROBE
+      if (tid == 0 && blockIdx.x < 2048) g_clk_pre[blockIdx.x][3] = __builtin_amdgcn_s_memtime() - clk_t0;
       unsigned long long acc_cmp = 0, acc_cbar = 0;
 #endif
       for (int t = 0; t < ni; ++t) {
@@ -673,6 +725,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 extern "C" int sdmi_dbg_read_phase(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_phase), (size_t)n * 48) == hipSuccess ? 0 : -5;
 }
+extern "C" int sdmi_dbg_read_pre(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_pre), (size_t)n * 80) == hipSuccess ? 0 : -5;
+}
 extern "C" int sdmi_dbg_read_clk(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk_probe), (size_t)n * 16) == hipSuccess ? 0 : -5;
 }
@@ -705,6 +760,7 @@ struct HCfg {
 
 template <class C>
 __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_bytes) {
+  sdmi_kernarg_warm<sizeof(GemmArgs) + 24>();     // + halo_bytes + the hidden grid size (gridDim.x)
   constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT, NS = C::NS;
   constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = C::G, NTAPH = C::NTAPH;
 #ifdef SDMI_CLK_PROBE
@@ -726,15 +782,17 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
     const int q = nwg >> 3, rr = nwg & 7;
     const int xcd = bid & 7, loc = bid >> 3;
     const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    kz = L / tiles;
-    tile = L - kz * tiles;
+    if (p.ksplit == 1) { kz = 0; tile = L; }
+    else { kz = L / tiles; tile = L - kz * tiles; }
   }
   // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
   // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
   // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
-  const int tiles_m = tiles / tiles_n;
-  const int tm = p.n_major ? tile % tiles_m : tile / tiles_n;
-  const int tn = p.n_major ? tile / tiles_m : tile % tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tdiv = p.n_major ? tiles_m : tiles_n;      // ONE scalar division (~30 instructions, ~300 cycles each on a lone wave)
+  const int tq = tile / tdiv, tr = tile - tq * tdiv;
+  const int tm = p.n_major ? tr : tq;
+  const int tn = p.n_major ? tq : tr;
   const int m0 = tm * BM, n0 = tn * BN;
   const int Cin = p.C0 + p.C1, nchunk = Cin >> 6;
   const int nkt = 9 * nchunk;
@@ -978,6 +1036,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
+  sdmi_kernarg_warm<sizeof(GemmArgs)>();
   const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
   const unsigned n8 = (unsigned)(p.N / 8);
   const size_t MN = (size_t)p.M * p.N;
@@ -1088,6 +1147,8 @@ struct CfgInfo {
   {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>, nullptr, 0, 0}
 #define CFG_ENTRY_W2(BM, BN, WM, WN, NS, TAG) \
   {"t" #BM "x" #BN "s" #NS "p" TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>, nullptr, 0, 0}
+#define CFG_ENTRY_Q(BM, BN, WM, WN, NS, PW) \
+  {"t" #BM "x" #BN "s" #NS "q" #PW, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::NT, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>>, nullptr, 0, 0}
 #define CFG_ENTRY_P2(BM, BN, WM, WN, NS, KPI) \
   {"t" #BM "x" #BN "s" #NS "p" #KPI, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, KPI>::NT, Cfg<BM, BN, WM, WN, NS, 2, KPI>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, KPI>>, nullptr, 0, 0}
 const CfgInfo kCfgs[] = {
@@ -1124,6 +1185,9 @@ const CfgInfo kCfgs[] = {
     // 32-row tiles, one head (128 columns) wide: the softmax GEMM of the folded cross-attention has only N / 128 = 8
     // n-tiles and no split-K, so at 16x16 / 8x8 (M = 512 / 128) the m-tile count is all the parallelism there is
     CFG_ENTRY_P(32, 128, 1, 4, 4), CFG_ENTRY_P(32, 128, 1, 4, 6), CFG_ENTRY(32, 128, 1, 4, 4),
+    // two producer waves per MFMA wave ("q2"): the K = C GEMMs' loop is paced by DMA issue per wave
+    CFG_ENTRY_Q(64, 64, 2, 2, 4, 2), CFG_ENTRY_Q(64, 64, 2, 2, 6, 2), CFG_ENTRY_Q(64, 128, 2, 2, 4, 2), CFG_ENTRY_Q(128, 64, 2, 2, 4, 2),
+    CFG_ENTRY_Q(128, 128, 2, 2, 3, 2), CFG_ENTRY_Q(128, 128, 2, 2, 4, 2),
 };
 #define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
   {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \

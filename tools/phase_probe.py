@@ -23,5 +23,13 @@ for cfgname in sys.argv[4:]:
     print(f"   WG start  (ns after first): median {np.median(st):.0f}  p90 {np.percentile(st, 90):.0f}  max {st.max():.0f}")
     print(f"   WG end    (ns after first): median {np.median(en):.0f}  p90 {np.percentile(en, 90):.0f}  max {en.max():.0f}")
     print(f"   WG life (ns): median {np.median(en - st):.0f}")
+    if hasattr(lib, "sdmi_dbg_read_pre"):
+        pb = (C.c_ulonglong * (10 * 2048))()
+        lib.sdmi_dbg_read_pre(pb, 2048)
+        pre = np.array(list(pb), dtype=np.float64).reshape(-1, 10)[:len(a)]
+        print("   producer: setup done %.0f, ring primed (issued) %.0f, first stage landed %.0f | consumer past first barrier %.0f (cycles, medians)"
+              % tuple(np.median(pre[:, i]) for i in range(4)))
+        print("   kernel arguments in the scalar cache after %.0f cycles" % np.median(pre[:, 4]))
+        print("   producer wave: tile map done %.0f, LayerNorm block %.0f, A row state %.0f, B pointers %.0f" % tuple(np.median(pre[:, i]) for i in (5, 6, 7, 8)))
     for i, nm in ((2, "setup"), (3, "K loop done"), (4, "tile in LDS"), (5, "stores retired")):
         print(f"   cycles to {nm:15s}: median {np.median(a[:, i]):.0f}")
