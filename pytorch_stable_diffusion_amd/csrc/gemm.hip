@@ -300,6 +300,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   sdmi_kernarg_warm<sizeof(GemmArgs) + 16>();     // + the hidden grid size this kernel reads (gridDim.x)
   // every argument the prologue needs, requested in ONE batch: left to itself the compiler loads each next to its first use behind
   // its own wait, and even scalar-cache hits then cost ~100 cycles apiece in series
+  if constexpr (C::NT < 1024)      // (the 16-wave kernels have 128 VGPRs per lane and no room for the SGPR pressure this adds)
   asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
                "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
                "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.X0), "s"(p.X1));
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   bool a_ok[RA];
   const f16* a_ptr[RA];
   int a_inc[RA];
-  const bool plain = p.ks == 1 && p.stride == 1 && p.ups == 0 && p.C1 == 0 && p.X0 == 0 && p.X1 == 0 && p.phase2 == 0;
+  const bool plain = C::NT < 1024 && p.ks == 1 && p.stride == 1 && p.ups == 0 && p.C1 == 0 && p.X0 == 0 && p.X1 == 0 && p.phase2 == 0;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int q = (i * SW + sw) * 64 + lane;
