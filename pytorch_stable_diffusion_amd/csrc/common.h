@@ -104,6 +104,11 @@ struct GemmArgs {
   int ksplit;
   int ksteps_per;
   int n_major;         // tile order inside a K-slice, set by the launcher (gemm.hip): 1 = consecutive tiles walk m first
+  // launcher-computed tile map (gemm.hip): tile = L % tiles, (tm, tn) from tile / tdiv with exact fixed-point reciprocals
+  // magic = floor(2^36 / d) + 1:  (n * magic) >> 36 == n / d  for n * d < 2^36, n < 2^22 (checked by the launcher) -- a scalar
+  // division is ~30 instructions of one wave, and there were three in front of the first tile request
+  int tiles, tdiv, plain;
+  unsigned long long tiles_magic, tdiv_magic;
   int act;             // epilogue after bias: 0 none, 1 quick-GELU x*sigmoid(1.702x) (sd/clip.py:170), 2 row softmax in the
                        //   log2 domain over the tile's 128 columns, columns >= sm_valid masked (one head of the folded
                        //   cross-attention per n-tile: BN = 128 configs only, fp16 output)

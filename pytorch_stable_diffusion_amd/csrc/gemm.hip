@@ -303,7 +303,8 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   if constexpr (C::NT < 1024)      // (the 16-wave kernels have 128 VGPRs per lane and no room for the SGPR pressure this adds)
   asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
                "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
-               "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.X0), "s"(p.X1));
+               "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.tiles), "s"(p.tdiv), "s"(p.plain),
+               "s"(p.tiles_magic), "s"(p.tdiv_magic));
 #ifdef SDMI_CLK_PROBE
   if (threadIdx.x == 0 && blockIdx.x < 2048) g_clk_pre[blockIdx.x][4] = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
@@ -323,22 +324,19 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   // 4 MiB L2.  Remap (bijectively) so each XCD owns a CONTIGUOUS range of (k-split, m-tile, n-tile)
   // ids: the 9 taps x n-tiles re-reads of an activation band then hit that XCD's L2.  Speed only.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles = tiles_n * ((p.M + BM - 1) / BM);
   int kz, tile;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, loc = bid >> 3;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    if (p.ksplit == 1) { kz = 0; tile = L; }
-    else { kz = L / tiles; tile = L - kz * tiles; }
+    kz = p.ksplit == 1 ? 0 : (int)(((unsigned long long)L * p.tiles_magic) >> 36);      // L / tiles
+    tile = L - kz * p.tiles;
   }
   // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
   // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
   // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tdiv = p.n_major ? tiles_m : tiles_n;      // ONE scalar division (~30 instructions, ~300 cycles each on a lone wave)
-  const int tq = tile / tdiv, tr = tile - tq * tdiv;
+  const int tq = (int)(((unsigned long long)tile * p.tdiv_magic) >> 36), tr = tile - tq * p.tdiv;   // tile / tdiv, no division
   const int tm = p.n_major ? tr : tq;
   const int tn = p.n_major ? tq : tr;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   bool a_ok[RA];
   const f16* a_ptr[RA];
   int a_inc[RA];
-  const bool plain = C::NT < 1024 && p.ks == 1 && p.stride == 1 && p.ups == 0 && p.C1 == 0 && p.X0 == 0 && p.X1 == 0 && p.phase2 == 0;
+  const bool plain = C::NT < 1024 && p.plain;      // (the 16-wave kernels have no registers to spare for a second path)
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int q = (i * SW + sw) * 64 + lane;
@@ -776,22 +774,19 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   const int wm = wave / C::WN, wn = wave % C::WN;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles = tiles_n * (p.M / BM);
   int kz, tile;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, rr = nwg & 7;
     const int xcd = bid & 7, loc = bid >> 3;
     const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    if (p.ksplit == 1) { kz = 0; tile = L; }
-    else { kz = L / tiles; tile = L - kz * tiles; }
+    kz = p.ksplit == 1 ? 0 : (int)(((unsigned long long)L * p.tiles_magic) >> 36);      // L / tiles (launcher-computed reciprocal)
+    tile = L - kz * p.tiles;
   }
   // tile order inside a K-slice (speed only): the 8 XCDs own CONTIGUOUS tile ranges.  m-major (n fastest) makes every XCD
   // stream all of W and 1/8 of A; n-major the reverse.  The launcher picks the order that moves fewer bytes through the
   // eight L2s (n-major when the weights are the larger operand: the 16x16 / 8x8 levels).
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tdiv = p.n_major ? tiles_m : tiles_n;      // ONE scalar division (~30 instructions, ~300 cycles each on a lone wave)
-  const int tq = tile / tdiv, tr = tile - tq * tdiv;
+  const int tq = (int)(((unsigned long long)tile * p.tdiv_magic) >> 36), tr = tile - tq * p.tdiv;
   const int tm = p.n_major ? tr : tq;
   const int tn = p.n_major ? tq : tr;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -1317,7 +1312,16 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
   p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
-  const int tiles = ((a.M + c.BM - 1) / c.BM) * ((a.N + c.BN - 1) / c.BN);
+  const int tiles_m = (a.M + c.BM - 1) / c.BM, tiles_n = (a.N + c.BN - 1) / c.BN;
+  const int tiles = tiles_m * tiles_n;
+  SDMI_REQUIRE((long long)tiles * p.ksplit < (1ll << 22) && (long long)tiles * tiles * p.ksplit < (1ll << 36),
+               "gemm: %d tiles x %d K-slices exceed the tile map's range", tiles, p.ksplit);
+  auto magic = [](int d) -> unsigned long long { return (1ull << 36) / (unsigned long long)d + 1ull; };
+  p.tiles = tiles;
+  p.tiles_magic = magic(tiles);
+  p.tdiv = p.n_major ? tiles_m : tiles_n;
+  p.tdiv_magic = magic(p.tdiv);
+  p.plain = !halo && p.ks == 1 && p.stride == 1 && p.ups == 0 && p.C1 == 0 && p.X0 == 0 && p.X1 == 0 && p.phase2 == 0;
   int dev = 0;
   SDMI_CHECK_HIP(hipGetDevice(&dev));
   SDMI_REQUIRE(dev >= 0 && dev < kMaxDev, "gemm: device index %d out of range", dev);
