@@ -1057,6 +1057,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
         rh = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + n);
       }
     }
+    // bias with the first slab loads (it was read element by element after the last slab: one more exposed latency)
+    f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { bv0 = *(const f32x4*)(p.bias + n); bv1 = *(const f32x4*)(p.bias + n + 4); }
     // four slabs' loads in flight at a time (a load-add-load-add chain paid one memory latency per slab); the
     // additions stay in slab order, so the result is bit-identical
     for (int z0 = 0; z0 < p.ksplit; z0 += 4) {
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     }
     if (p.bias) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+      for (int e = 0; e < 4; ++e) { v[e] += bv0[e]; v[4 + e] += bv1[e]; }
     }
     if (n < p.cs_hi) {
 #pragma unroll

@@ -177,9 +177,13 @@ constexpr int GNF_NT = 512;
 template <int MAXQ, bool SLAB>
 __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
   __shared__ float s_w[2][GNF_NT / 64];
+  __shared__ __attribute__((aligned(16))) float s_gb[2][128];        // this group's gamma / beta (cpg <= 128)
   const int C = p.C0 + p.C1, cpg = C / 32, q4 = cpg / 4;
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int total = p.P * q4;
+  // the layer's own gamma / beta come from HBM: requested here, with the slab, instead of next to their use behind the two
+  // reductions (that was one more exposed memory latency per launch); visible after the reductions' barriers
+  if (tid < cpg) { s_gb[0][tid] = p.gamma[g * cpg + tid]; s_gb[1][tid] = p.beta[g * cpg + tid]; }
   f32x4 v[MAXQ];
   float s = 0.f;
   // slot = tid + i*NT walks (pixel, channel quad) incrementally: one integer division per thread instead of one per
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
     const int slot = tid + i * GNF_NT;
     if (slot < total) {
       const int c = g * cpg + 4 * j;
-      const f32x4 ga = *(const f32x4*)(p.gamma + c), be = *(const f32x4*)(p.beta + c);
+      const f32x4 ga = *(const f32x4*)(&s_gb[0][4 * j]), be = *(const f32x4*)(&s_gb[1][4 * j]);
       f16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -378,7 +382,7 @@ int sdmi_gn_launches(const GnArgs& a) {
   static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 1024;   // up to 32x32 the one launch is as fast as stats + apply (same-box 4.277 vs 4.281 ms/step, 11 launches fewer); beyond, 64 blocks cannot pull the map fast enough
   const int C = a.C0 + a.C1, cpg = C / 32;
   const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
-  return (cpg % 4 == 0 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
+  return (cpg % 4 == 0 && cpg <= 128 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
 }
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
