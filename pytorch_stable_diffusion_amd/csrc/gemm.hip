@@ -297,14 +297,16 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  sdmi_kernarg_warm<sizeof(GemmArgs) + 16>();     // + the hidden grid size this kernel reads (gridDim.x)
   // every argument the prologue needs, requested in ONE batch: left to itself the compiler loads each next to its first use behind
-  // its own wait, and even scalar-cache hits then cost ~100 cycles apiece in series
-  if constexpr (C::NT < 1024)      // (the 16-wave kernels have 128 VGPRs per lane and no room for the SGPR pressure this adds)
-  asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
-               "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
-               "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.tiles), "s"(p.tdiv), "s"(p.plain),
-               "s"(p.tiles_magic), "s"(p.tdiv_magic));
+  // its own wait -- a dozen serial scalar-cache misses (the launch's kernarg slot is new memory), and even hits cost ~100 cycles
+  // apiece in series.  The batch touches every 64-byte line of the struct (p.bias: the epilogue's line), so the later loads hit.
+  if constexpr (C::NT < 1024)
+    asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
+                 "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
+                 "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.tiles), "s"(p.tdiv), "s"(p.plain),
+                 "s"(p.tiles_magic), "s"(p.tdiv_magic), "s"(p.bias));
+  else      // the 16-wave kernels have 128 VGPRs per lane and no room for the SGPR pressure of the batch: warm the lines only
+    sdmi_kernarg_warm<sizeof(GemmArgs) + 16>();     // + the hidden grid size this kernel reads (gridDim.x)
 #ifdef SDMI_CLK_PROBE
   if (threadIdx.x == 0 && blockIdx.x < 2048) g_clk_pre[blockIdx.x][4] = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
