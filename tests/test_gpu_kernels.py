@@ -71,6 +71,25 @@ def test_gemm_random_bias_residual(M, Nn, K, ksplit):
         assert (out_h.cpu().double() - ref_h).abs().max().item() < 8e-3
 
 
+@pytest.mark.parametrize("M,Nn,K", [(200, 136, 256), (2048, 640, 640), (512, 1280, 1280)])
+def test_every_tile_config_gives_the_same_bits_without_split_k(M, Nn, K):
+    """A plan may change the tile config of a shape (tools/retune.sh); without split-K that must not change a single bit: every
+    output element is accumulated over K in k16-step order by ONE wave whatever the tile shape, ring depth, producer-wave
+    count or K-steps per barrier.  (Split-K regroups the sum; the halo kernels walk K chunk-major: both have their own tests.)"""
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a = torch.randn((M, K), generator=g).to(torch.float16).to(DEV)
+    w = (torch.randn((Nn, K), generator=g) / math.sqrt(K)).to(torch.float16).to(DEV)
+    bias = torch.randn((Nn,), generator=g).to(DEV)
+    res = torch.randn((M, Nn), generator=g).to(DEV)
+    ref, ref_cfg = None, None
+    for cfg in _plain_cfgs():
+        out = G.igemm(a.view(1, M, 1, K), w, B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias, res=res, out_f32=True, cfg=cfg, ksplit=1)
+        if ref is None:
+            ref, ref_cfg = out.clone(), cfg
+        else:
+            assert torch.equal(out, ref), f"config {cfg} differs from config {ref_cfg}: max {(out - ref).abs().max().item():.3e}"
+
+
 def _conv_ref(x_nhwc, w_oihw, stride, ups):
     x = x_nhwc.float().permute(0, 3, 1, 2)
     if ups:
