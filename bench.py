@@ -183,6 +183,17 @@ def main():
         torch.cuda.synchronize()
         pr = h.profile_read()
         h.profile(False)
+        # An event pair around a launch measures the kernel plus the pair's own cost.  The four classes cover every launch of a
+        # step but three (stem, final conv, CFG + DDPM), and in the un-instrumented step the kernels run back to back (their
+        # rocprofv3 durations add up to its wall time), so  (sum of the classes' event times - the timed region's step time) /
+        # instrumented launches  is that cost per pair (a slight under-estimate: the three unclassed kernels stay in the step
+        # time).  It is taken back out of each family's time; the corrected durations agree with the rocprofv3 kernel trace of
+        # the same command (profiles/r03_step_by_shape.txt), the raw ones are kept beside them.
+        n_instr = sum(pr[c]["launches"] for c in pr)
+        ev_overhead_ms = max(0.0, sum(pr[c]["ms"] for c in pr) - ev_ms / args.steps * nprof) / max(n_instr, 1)
+        raw_ms = {c: pr[c]["ms"] for c in pr}
+        for c in pr:
+            pr[c]["ms"] = max(pr[c]["ms"] - ev_overhead_ms * pr[c]["launches"], 1e-6)
         mf, fin = pr["mfma"], pr["finalize"]
         achieved = mf["flops"] / (mf["ms"] * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
         achieved_fin = mf["flops"] / ((mf["ms"] + fin["ms"]) * 1e-3) / 1e12 if mf["ms"] > 0 else 0.0
@@ -230,6 +241,10 @@ def main():
             "launches_per_step": mf["launches"] // nprof,
             "gflop_per_step": round(mf["flops"] / nprof / 1e9, 2),
             "ms_per_step": round(mf["ms"] / nprof, 3),
+            "timing": {"method": "HIP event pair per launch on the forward's stream, minus the pairs' own cost (sum of all classes vs the timed step)",
+                       "event_overhead_us_per_launch": round(ev_overhead_ms * 1e3, 2),
+                       "raw_ms_per_step": round(raw_ms["mfma"] / nprof, 3),
+                       "raw_achieved": round(mf["flops"] / (raw_ms["mfma"] * 1e-3) / 1e12, 2) if raw_ms["mfma"] > 0 else None},
             "with_finalize": {"achieved": round(achieved_fin, 2), "frac": round(achieved_fin / PEAK_TFLOPS_F16, 4),
                               "launches_per_step": (mf["launches"] + fin["launches"]) // nprof,
                               "ms_per_step": round((mf["ms"] + fin["ms"]) / nprof, 3), "traffic": traffic_fin,
