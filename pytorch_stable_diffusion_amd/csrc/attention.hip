@@ -58,21 +58,51 @@ struct ACfg {
   static constexpr int EXTRA = SPARE ? 16 : 0;     // the K-side bias fragment behind the stages
 };
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant): n LDS-DMA instructions may stay in flight
+__device__ __forceinline__ void wait_vm_upto(int n) {
+#define SDMI_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    SDMI_VM_CASE(1) SDMI_VM_CASE(2) SDMI_VM_CASE(3) SDMI_VM_CASE(4) SDMI_VM_CASE(5) SDMI_VM_CASE(6) SDMI_VM_CASE(7) SDMI_VM_CASE(8)
+    SDMI_VM_CASE(9) SDMI_VM_CASE(10) SDMI_VM_CASE(11) SDMI_VM_CASE(12) SDMI_VM_CASE(13) SDMI_VM_CASE(14) SDMI_VM_CASE(15) SDMI_VM_CASE(16)
+    SDMI_VM_CASE(17) SDMI_VM_CASE(18) SDMI_VM_CASE(19) SDMI_VM_CASE(20) SDMI_VM_CASE(21) SDMI_VM_CASE(22) SDMI_VM_CASE(23) SDMI_VM_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SDMI_VM_CASE
+}
+
 // NW = waves per workgroup: 4, or 8 for the key-split form over 128 queries (long sequences: four waves per SIMD at the
-// same K/V bytes staged per query as the unsplit form)
-template <int D, bool SPLIT, int NW = 4>
+// same K/V bytes staged per query as the unsplit form).
+// NB = depth of the K/V ring in LDS.  2: the tiles of step t+1 are requested when step t starts and waited for (vmcnt(0)) when it
+// ends.  3: the tiles of step t+2 are requested when step t starts, and the wait at the end of step t is a COUNTED one for step
+// t+1's tiles only (requested a whole step earlier) -- the newest stage stays in flight across the barrier.
+// Grid: ONE dimension, remapped so that every XCD owns a contiguous range of (batch*head, query tile) ids: workgroups are dealt
+// round-robin to the 8 XCDs, so with the plain (query tile, batch*head) grid the 32 query tiles of one head landed on all
+// eight L2s and every L2 streamed every head's K and V (measured: 89 MB fetched per S = 4096 launch for 15.7 MB of Q/K/V).
+// With two heads per XCD their K/V (1.3 MB) stay in that XCD's L2.  Speed only: any placement gives the same result.
+template <int D, bool SPLIT, int NW = 4, int NB = 2>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs p) {
   typedef ACfg<D> C;
   static_assert(NW == 4 || (SPLIT && NW == 8), "8-wave workgroups only in the key-split form");
+  static_assert(NB == 2 || NB == 3, "ring depth");
   constexpr int NSUB = SPLIT ? 2 : 1;                 // key streams staged per step (SPLIT: one tile of each half)
   constexpr int STAGE2 = NSUB * C::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / p.H, head = bh % p.H;
+  int qtile, bh;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;      // bijective (cdna guide T1)
+    const int ntq = SPLIT ? p.Sq / (NW * 16) : (p.Sq + 127) >> 7;
+    bh = L / ntq;
+    qtile = L - bh * ntq;
+  }
+  const int b = bh / p.H, head = bh % p.H;
   const int hk = SPLIT ? (wave & 1) : 0;              // which half of the keys this wave reduces
-  const int q0 = SPLIT ? blockIdx.x * (NW * 16) + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+  const int q0 = SPLIT ? qtile * (NW * 16) + (wave >> 1) * 32 : qtile * 128 + wave * 32;
   const int ntiles = SPLIT ? (p.Skv >> 7) : (p.Skv + 63) >> 6;   // tiles per stream (SPLIT: Skv % 128 == 0, launcher)
 
   const f16* kbase = p.k + (size_t)b * p.k_batch_stride * p.ldk + head * D;
@@ -107,6 +137,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   }
   const size_t kstep = (size_t)64 * p.ldk;
   int stage_key0 = 0;
+  // LDS-DMA instructions THIS wave issues per stage() call (wave-uniform; the waves differ where K_INST / V_INST % NW != 0)
+  int per_stage = 0;
+#pragma unroll
+  for (int i = 0; i < KI; ++i) per_stage += (i * NW + wave < C::K_INST) ? NSUB : 0;
+#pragma unroll
+  for (int i = 0; i < VI; ++i) per_stage += (C::V_INST % NW == 0 || i * NW + wave < C::V_INST) ? NSUB : 0;
 
   auto stage = [&](int buf) {
 #pragma unroll
@@ -180,13 +216,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   if (h == (C::SPARE ? 1 : 0)) kbias[0] = (f16)1.f;
   // SPARE: the h = 1 lanes of the last k16 step read their K fragment {1, 0, ..., 0} from 16 bytes behind the K/V stages (one
   // select on the LDS address instead of four on the loaded registers); visible after the first __syncthreads()
-  const char* const kbias_lds = smem + 2 * STAGE2;
+  const char* const kbias_lds = smem + NB * STAGE2;
   if (C::SPARE && tid == 0) {
     f16x8 one;
 #pragma unroll
     for (int e = 0; e < 8; ++e) one[e] = (f16)0.f;
     one[0] = (f16)1.f;
-    *(f16x8*)(smem + 2 * STAGE2) = one;
+    *(f16x8*)(smem + NB * STAGE2) = one;
   }
 
   // one 64-key tile: S'^T = K Q'^T - m_run, online softmax, O^T += V^T P^T.  FIRST: tile 0 (m_run not set yet).
@@ -289,21 +325,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   };
 
   stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (NB == 3 && ntiles > 1) {
+    stage(1);
+    wait_vm_upto(per_stage);              // tile 0 has landed, tile 1 may still fly
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the K-side bias fragment written above
+  __builtin_amdgcn_s_barrier();                           // (a raw barrier: __syncthreads() would drain the second stage)
   const bool ragged = !SPLIT && (p.Skv & 63) != 0;
   const int nfull = (!SPLIT && p.causal) ? 0 : (ragged ? ntiles - 1 : ntiles);   // tiles that need no masking
   // Three runs of tiles, each with ONE body in its loop (separate loops keep the accumulators in place: with both
   // bodies in one loop the register allocator copied all of O^T every tile): tile 0, unmasked tiles, masked tail.
-  int cur = 0;
+  int cur = 0, nxt = NB - 1;
   auto step = [&](int t, auto masked_tag, auto first_tag) {
-    if (!(SDMI_ATTN_ABLATE & 8) && t + 1 < ntiles) stage(cur ^ 1);
+    // the buffer written here was last read in step t-1 (NB = 3: it holds tile t+2, NB = 2: tile t+1); the barrier that ended
+    // step t-1 closed that WAR window
+    if (!(SDMI_ATTN_ABLATE & 8) && t + NB - 1 < ntiles) stage(nxt);
     tile_body(masked_tag, first_tag, t, cur);
     if (!(SDMI_ATTN_ABLATE & 16) && t + 1 < ntiles) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // RAW for step t+1: every wave waits for ITS pieces of tile t+1, then the barrier publishes them.  NB = 3: the stage
+      // issued in this step (tile t+2) stays in flight -- a plain s_barrier, not __syncthreads(), whose fence would drain it
+      if (NB == 3 && t + 2 < ntiles) wait_vm_upto(per_stage);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    cur ^= 1;
+    cur = cur + 1 == NB ? 0 : cur + 1;
+    nxt = nxt + 1 == NB ? 0 : nxt + 1;
   };
   if (nfull > 0) step(0, std::false_type{}, std::true_type{});
   else step(0, std::true_type{}, std::true_type{});
@@ -367,11 +416,19 @@ int launch(const AttnArgs& a, hipStream_t st) {
   int dev = 0;
   SDMI_CHECK_HIP(hipGetDevice(&dev));
   SDMI_REQUIRE(dev >= 0 && dev < 16, "attention: device index %d out of range", dev);
+  // ring depth 3 where the LDS allows it at the occupancy the form is built for: d = 40 (two 8-wave workgroups per CU: 78 KB
+  // each) and d = 80 split (one workgroup per CU either way); d = 160 split fills the LDS with two stages.  SDMI_ATTN_NB=2: A/B
+  static const bool nb3 = !(getenv("SDMI_ATTN_NB") && atoi(getenv("SDMI_ATTN_NB")) == 2);
+  constexpr bool CAN3 = 3 * 2 * C::STAGE + C::EXTRA <= (D == 40 ? 80 * 1024 : 160 * 1024);
   if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + C::EXTRA));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS + C::EXTRA));
-    if constexpr (D == 40)
+    if constexpr (CAN3)
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * C::LDS + C::EXTRA));
+    if constexpr (D == 40) {
       SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS + C::EXTRA));
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, true, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * C::LDS + C::EXTRA));
+    }
     attr_done[dev] = true;
   }
   // key-split form for short self-attention (see the header): both halves whole 64-key tiles, whole 64-query workgroups
@@ -381,16 +438,24 @@ int launch(const AttnArgs& a, hipStream_t st) {
   // long sequences (d = 40, S = 4096): 128-query workgroups of EIGHT waves, the wave pairs again splitting the keys: the K/V
   // bytes staged per query equal the unsplit form's, and four waves per SIMD hide each other's dependent tile chains
   static const int split8_min = getenv("SDMI_ATTN_SPLIT8_MINS") ? atoi(getenv("SDMI_ATTN_SPLIT8_MINS")) : 2048;
+  // all grids are one-dimensional: (query tiles) x (batch * heads) ids, decoded XCD-aware inside the kernel
+  const int BH = a.B * a.H;
   if (D == 40 && split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 128 == 0 && a.Sq >= split8_min) {
     if constexpr (D == 40) {
-      dim3 grid(a.Sq / 128, a.B * a.H);
-      hipLaunchKernelGGL((attn_kernel<D, true, 8>), grid, dim3(512), 2 * C::LDS + C::EXTRA, st, a);
+      dim3 grid(a.Sq / 128 * BH);
+      if (nb3) hipLaunchKernelGGL((attn_kernel<D, true, 8, 3>), grid, dim3(512), 3 * C::LDS + C::EXTRA, st, a);
+      else hipLaunchKernelGGL((attn_kernel<D, true, 8>), grid, dim3(512), 2 * C::LDS + C::EXTRA, st, a);
     }
   } else if (split_on && !a.causal && a.Skv % 128 == 0 && a.Sq % 64 == 0 && a.Sq <= split_max && 2 * C::LDS + C::EXTRA <= 160 * 1024) {
-    dim3 grid(a.Sq / 64, a.B * a.H);
-    hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
+    dim3 grid(a.Sq / 64 * BH);
+    if constexpr (CAN3) {
+      if (nb3) hipLaunchKernelGGL((attn_kernel<D, true, 4, 3>), grid, dim3(256), 3 * C::LDS + C::EXTRA, st, a);
+      else hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
+    } else {
+      hipLaunchKernelGGL((attn_kernel<D, true>), grid, dim3(256), 2 * C::LDS + C::EXTRA, st, a);
+    }
   } else {
-    dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+    dim3 grid((a.Sq + 127) / 128 * BH);
     // diagnostic knob (A/B only): extra dynamic LDS per workgroup caps the workgroups per CU, i.e. the waves per SIMD
     static const int lds_pad = getenv("SDMI_ATTN_LDS_PAD") ? atoi(getenv("SDMI_ATTN_LDS_PAD")) : 0;
     if (lds_pad > 0) {

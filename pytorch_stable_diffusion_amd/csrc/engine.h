@@ -178,6 +178,7 @@ struct Engine {
   int flags = 0;
   int device = -1;            // HIP device the handle (weights, arena, plans) lives on
   bool stream_f32 = false, partial = false, tune = true;
+  bool is_lane = false;       // made by sdmi_unet_clone: borrows its parent's weights, never tunes (plan_of)
   std::vector<void*> owned;   // hipMalloc'd blocks
   int64_t weight_bytes = 0;
   std::map<std::string, sdmi_tensor_desc> src;
@@ -329,6 +330,10 @@ struct Engine {
       return SDMI_EINVAL;
     }
     st = (hipStream_t)stream;
+    // a deferred split-K combine never outlives the call that made it (run_stage flushes); if that call FAILED between the
+    // conv and its GroupNorm the flag would still be up, and the next entry's first launch would run splitk_finalize on
+    // slabs and arena addresses of the failed forward
+    pend = false;
     return SDMI_OK;
   }
 
@@ -582,7 +587,10 @@ struct Engine {
           // shared by engines with different slab sizes, and a hand-edited line must not write past the slab)
           if (have && !ksplit_ok(a, pl.cfg, pl.ksplit)) have = false;
         }
-        if (!have) {
+        // a LANE (sdmi_unet_clone) never times anything: its kernels share the GPU with the other lanes' streams, the cold-L2
+        // timings would be distorted and then persisted for every later process.  It runs what its parent tuned (copied at
+        // clone time, or found in the store above once the parent has appended it), else the heuristic tile -- unrecorded
+        if (!have && !is_lane) {
           TRY(tune_gemm(a, &pl));
           ++tuned_shapes;
           if (pl.cfg >= 0) ps.append(key, sdmi_gemm_cfg_name(pl.cfg), pl.ksplit, pl.us);

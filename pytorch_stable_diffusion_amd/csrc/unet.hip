@@ -245,6 +245,7 @@ int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out) {
   }
   sdmi_unet* u = new sdmi_unet();
   u->flags = src->flags; u->stream_f32 = src->stream_f32; u->partial = src->partial; u->tune = src->tune;
+  u->is_lane = true;
   u->weight_bytes = 0;                                   // borrowed
   u->res = src->res; u->attn = src->attn; u->convs = src->convs;
   u->te1 = src->te1; u->te2 = src->te2; u->has_time = src->has_time; u->time_total = src->time_total;

@@ -21,6 +21,8 @@ class Diffusion:
         self._device = torch.device("cpu")
         self._handle = None
         self._ctx_key = None
+        self._parent = None
+        self._lanes = []
         self.stream_f32 = stream_f32
         self.autotune = autotune
 
@@ -34,6 +36,7 @@ class Diffusion:
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for Diffusion: missing {missing[:5]}"
                                f"{'...' if len(missing) > 5 else ''} unexpected {unexpected[:5]}")
+        self._refuse_on_lane("load_state_dict")
         for k, shape in self._manifest.items():
             if k in state:
                 if tuple(state[k].shape) != tuple(shape):
@@ -45,6 +48,7 @@ class Diffusion:
     def to(self, device):
         device = normalize_device(device)
         if device != self._device:
+            self._refuse_on_lane("to(another device)")
             # fp16 copies on the GPU (the packer casts anyway); CPU copies stay as given
             for k in list(self._state.keys()):
                 self._state[k] = self._state[k].to(device)
@@ -67,21 +71,44 @@ class Diffusion:
         self._handle = None
         self._ctx_key = None
 
-    def lane(self) -> "Diffusion":
+    def _refuse_on_lane(self, what: str):
+        """A lane shares its parent's state dict BY REFERENCE and borrows the parent's packed weights: moving or replacing
+        the tensors through a lane would change them under the parent (whose handle and device would not follow)."""
+        if getattr(self, "_parent", None) is not None:
+            raise RuntimeError(f"Diffusion lane: {what} must be called on the parent model (lanes borrow its weights)")
+
+    def lane(self, index: Optional[int] = None) -> "Diffusion":
         """A second LANE of this model: same weights (the packed copies on the GPU are shared, nothing is re-packed), own
         activation arena / context / schedule.  Two lanes driven on two HIP streams run two independent generate() loops
         concurrently on one GPU and fill each other's per-launch latency (``replicas.run_prompts(streams_per_gpu=2)``).
-        The lane is dropped with this model's handle."""
+        ``index``: reuse lane number ``index`` (0-based among the extra lanes) when it already exists instead of making
+        another one -- a lane holds a 6 GiB arena, so callers that come back (a service loop) must not pile them up.
+        Lanes are dropped with this model's handle or by ``release_lanes()``."""
+        self._refuse_on_lane("lane()")
+        if not hasattr(self, "_lanes"):
+            self._lanes = []
+        if index is not None and 0 <= index < len(self._lanes):
+            return self._lanes[index]
         ln = Diffusion.__new__(Diffusion)
         ln._manifest, ln._state, ln._device = self._manifest, self._state, self._device
         ln.stream_f32, ln.autotune = self.stream_f32, self.autotune
         ln._ctx_key = None
         ln._lanes = []
+        ln._parent = self
         ln._handle = self.handle().clone()
-        if not hasattr(self, "_lanes"):
-            self._lanes = []
         self._lanes.append(ln)
         return ln
+
+    def lanes(self, n: int):
+        """[self, lane 0, ..., lane n-2]: ``n`` concurrent denoising loops over one copy of the packed weights; existing lanes
+        are reused, missing ones created."""
+        return [self] + [self.lane(i) for i in range(max(0, n - 1))]
+
+    def release_lanes(self):
+        """Free every lane's arena / slabs / context buffers (the parent keeps its own)."""
+        for ln in getattr(self, "_lanes", []):
+            ln._drop_handle()
+        self._lanes = []
 
     # ---- native handle -----------------------------------------------------------------------------
     def handle(self):

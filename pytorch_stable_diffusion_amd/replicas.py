@@ -63,6 +63,40 @@ def broadcast_weights(flat: torch.Tensor, src: int = 0, group=None, chunk_elems:
         dist.broadcast(flat[s:min(n, s + chunk_elems)], src=src, group=group)
 
 
+def timed_broadcast(flat: torch.Tensor, src: int = 0, group=None, device=None) -> Optional[Dict[str, float]]:
+    """``broadcast_weights`` with its wall time: {"bytes", "seconds" (max over ranks), "GB_per_s"}; None without a group."""
+    import time
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    on_gpu = flat.is_cuda
+    dist.barrier(group)
+    if on_gpu:
+        torch.cuda.synchronize(flat.device)
+    t0 = time.perf_counter()
+    broadcast_weights(flat, src=src, group=group)
+    if on_gpu:
+        torch.cuda.synchronize(flat.device)
+    dt = max_over_ranks(time.perf_counter() - t0, device=device if device is not None else (flat.device if on_gpu else None), group=group)
+    nbytes = flat.numel() * flat.element_size()
+    return {"bytes": nbytes, "seconds": round(dt, 4), "GB_per_s": round(nbytes / dt / 1e9, 2) if dt > 0 else None}
+
+
+def group_facts(my_rate: float, device=None, group=None) -> Dict[str, object]:
+    """What the process group itself reports: backend name, ranks counted by an all-reduce of 1, and every rank's own rate
+    (all-gather).  Without a group: backend None, one rank."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {"backend": None, "ranks_seen": 1, "per_rank": [round(float(my_rate), 3)]}
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    mine = torch.tensor([my_rate], dtype=torch.float64, device=device)
+    rates = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(rates, mine, group=group)
+    return {"backend": dist.get_backend(group), "ranks_seen": int(round(one.item())),
+            "per_rank": [round(float(r.item()), 3) for r in rates]}
+
+
 def shard_prompts(items: Sequence, rank: int, world: int) -> List:
     """Prompt/seed i -> rank i mod world."""
     return [it for i, it in enumerate(items) if i % world == rank]
@@ -166,20 +200,25 @@ class _Serialised:
             return out
 
 
-def lane_models(models: Dict[str, object], n_lanes: int) -> List[Dict[str, object]]:
+def lane_models(models: Dict[str, object], n_lanes: int, device=None) -> List[Dict[str, object]]:
     """``n_lanes`` model dicts for concurrent generate() loops on ONE GPU: every lane shares the CLIP / VAE objects of
-    ``models`` (serialised: one caller at a time); lane 0 drives ``models["diffusion"]`` itself, the others their own lane of
-    it (``Diffusion.lane()``: shared packed weights, own scratch)."""
+    ``models`` (serialised: one caller at a time); lane 0 drives ``models["diffusion"]`` itself, the others a lane of it
+    (``Diffusion.lanes()``: shared packed weights, own scratch).  Lanes are REUSED across calls -- each holds a 6 GiB arena,
+    so a service loop that called this once per batch used to leak one arena per extra lane per call -- and
+    ``models["diffusion"].release_lanes()`` frees them.  ``device``: the model is moved there first (a lane cannot move)."""
     import threading
     if n_lanes <= 1:
         return [models]
     lock = threading.Lock()
     shared = {k: _Serialised(v, lock) for k, v in models.items() if k != "diffusion"}
+    unet = models["diffusion"]
+    if device is not None and hasattr(unet, "to"):
+        unet.to(device)
+    units = unet.lanes(n_lanes) if hasattr(unet, "lanes") else [unet] * n_lanes
     out = []
     for i in range(n_lanes):
         d = dict(shared)
-        unet = models["diffusion"]
-        d["diffusion"] = unet if i == 0 or not hasattr(unet, "lane") else unet.lane()
+        d["diffusion"] = units[i]
         out.append(d)
     return out
 
@@ -205,7 +244,7 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     todo = shard_prompts(list(enumerate(prompts)), rank, world)
     on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
     n_lanes = max(1, min(int(streams_per_gpu), len(todo))) if todo else 1
-    lanes = lane_models(models, n_lanes)
+    lanes = lane_models(models, n_lanes, device=device)
     results: Dict[int, torch.Tensor] = {}
     per_image: Dict[int, float] = {}
     errors: List[BaseException] = []

@@ -258,3 +258,36 @@ def test_checkpoint_path_on_gpu_matches_direct_load(models, tmp_path):
     a = pipeline.generate(models=loaded, **kw)
     b = pipeline.generate(models=models, **kw)
     assert a.shape == (512, 512, 3) and np.array_equal(a, b)
+
+
+def test_run_prompts_lanes_do_not_leak_device_memory(models):
+    """replicas.run_prompts(streams_per_gpu=2) twice: the second call reuses the first call's lane (a lane holds a 6 GiB arena,
+    a 96 MiB slab and its context buffers; round 3 made a new one per call), and release_lanes() gives the memory back."""
+    from pytorch_stable_diffusion_amd import replicas
+    m = dict(models)
+    m["decoder"] = models["decoder"].inner
+    unet = m["diffusion"]
+    unet.release_lanes()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    kw = dict(seed_base=3, n_inference_steps=2, height=256, width=256, streams_per_gpu=2)
+    a, _ = replicas.run_prompts(["a dog", "a cat"], m, StubTokenizer(), DEV, **kw)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert len(unet._lanes) == 1
+    b, _ = replicas.run_prompts(["a dog", "a cat"], m, StubTokenizer(), DEV, **kw)
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert len(unet._lanes) == 1 and free1 - free2 < (256 << 20), f"second call took {(free1 - free2) >> 20} MiB more"
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert free0 - free1 > (4 << 30)                       # the lane's arena really lives on the device ...
+    unet.release_lanes()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    assert free3 - free2 > (4 << 30)                       # ... and comes back
+    lane = unet.lane()
+    with pytest.raises(RuntimeError):
+        lane.to("cpu")
+    with pytest.raises(RuntimeError):
+        lane.load_state_dict(unet.state_dict())
+    unet.release_lanes()

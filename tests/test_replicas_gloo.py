@@ -37,7 +37,10 @@ def _worker(rank, world, port, q):
         g_ok = True
         if rank == 0:
             g_ok = all(int(g[0, 0, 0]) == i for i, g in enumerate(gathered))
-        q.put((rank, ok, mine, tmax, g_ok))
+        # the bench line's self-check fields (bench.py: dist_backend / ranks_seen / per_rank_steps_per_s / weight_broadcast)
+        facts = replicas.group_facts(10.0 + rank)
+        tb = replicas.timed_broadcast(flat, src=0)
+        q.put((rank, ok, mine, tmax, g_ok, facts, tb))
     finally:
         dist.destroy_process_group()
 
@@ -58,6 +61,12 @@ def test_replica_plumbing_world2():
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
     assert res[0][3] == res[1][3] == 2.0
     assert res[0][4]
+    for r in res:
+        assert r[5] == {"backend": "gloo", "ranks_seen": 2, "per_rank": [10.0, 11.0]}
+        assert r[6]["bytes"] > 0 and r[6]["seconds"] > 0 and r[6]["GB_per_s"] is not None
+    assert res[0][6] == res[1][6]                       # max-over-ranks time: every rank reports the same line
+    assert replicas.group_facts(3.0) == {"backend": None, "ranks_seen": 1, "per_rank": [3.0]}     # no group: one rank
+    assert replicas.timed_broadcast(torch.zeros(8)) is None
 
 
 def test_flat_layout_alignment():
