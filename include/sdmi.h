@@ -180,8 +180,19 @@ typedef struct sdmi_gemm_desc {
    * same accumulator (the composed feed-forward).  With ksplit > 1 the K-slices must end on that boundary and
    * ln_out ([M][2] fp32 scratch) must be given. */
   int ln_ksteps; float* ln_out;
+  /* gacc != NULL: the launch also leaves the GroupNorm statistics of what it writes (sd/diffusion.py:173,199,294: every
+   * GroupNorm input is a conv / linear output): per image, per block of rows one workgroup owns ("record row") and per atom of
+   * gacc_atom consecutive channels the moments {sum, sum of squares} as float2,
+   *   gacc[((image * T + t) * (N / gacc_atom) + atom) * parts + part]
+   * with T and parts as sdmi_op_gemm_stat_layout reports them for this descriptor (parts = 2: an atom that straddles two column
+   * tiles has its moments split over the two parts; they add up).  Plain stores, every slot written exactly once: nothing to
+   * zero, no dependence on workgroup order.  gacc_rows_img = rows (pixels) per image; the row blocks never straddle images. */
+  float* gacc; int gacc_atom; int gacc_rows_img;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
+/* record rows per image (T) and parts of the statistics the launch described by d writes to d->gacc (d->gacc != NULL);
+ * the buffer needs images * T * (N / gacc_atom) * parts float2.  Fails when the tile config / split-K of d cannot take them. */
+int sdmi_op_gemm_stat_layout(const sdmi_gemm_desc* d, int* T, int* parts);
 /* iters back-to-back launches of the same GEMM between two HIP events -> microseconds per launch; iters < 0: -iters launches
  * timed one by one with the L2s evicted before each (64 MiB fill), minimum returned */
 int sdmi_bench_gemm(const sdmi_gemm_desc* d, int iters, float* us_per_iter, void* stream);
@@ -213,6 +224,8 @@ typedef struct sdmi_b2b_desc {
    * partial statistics sdmi_op_gn_stats wrote ([B][gn_nchunk][32][2]); images of S rows, S % 32 == 0; a1 is ignored. */
   const void* gx; int gx_f32;
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
+  /* GroupNorm statistics of `out` as in sdmi_gemm_desc (one-pass form, 32-row tiles: M <= 8192): T = gacc_rows_img / 32, parts = 1 */
+  float* gacc; int gacc_atom; int gacc_rows_img;
 } sdmi_b2b_desc;
 int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* stream);
 int sdmi_gemm_num_configs(void);
@@ -246,6 +259,12 @@ int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1
 int sdmi_op_groupnorm_slab(const float* slab, int ksplit, const float* bias, const void* res, int res_f32, int C, int B, int P,
                            const float* gamma, const float* beta, float eps, int silu, void* y_f16, float* out32, void* out16,
                            void* stream);
+/* GroupNorm(32)(+SiLU) whose statistics were left behind by the producers of x0 / x1 (sdmi_gemm_desc::gacc): one normalising
+ * pass, no statistics launch.  rec0 / rec1 with their T and parts as the producers wrote them; (c0 + c1) / 32 and c0 are
+ * multiples of atom, at most 8 atoms per group. */
+int sdmi_op_groupnorm_acc(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, const float* rec0, int T0,
+                          int parts0, const float* rec1, int T1, int parts1, int atom, const float* gamma, const float* beta,
+                          float eps, int silu, void* y_f16, void* stream);
 int sdmi_op_layernorm(const void* x, int in_f32, int M, int C, const float* gamma, const float* beta, float eps,
                       void* y_f16, void* stream);
 /* GroupNorm statistics only: per (image, pixel chunk, group) partial {sum, sum of squares} into partial_out

@@ -36,7 +36,8 @@ class GemmDesc(C.Structure):
                 ("ln_c", C.c_int), ("ln_eps", C.c_float), ("out_t_perm", C.c_int),
                 ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
                 ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int),
-                ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p)]
+                ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p),
+                ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int)]
 
 
 class B2bDesc(C.Structure):
@@ -47,7 +48,8 @@ class B2bDesc(C.Structure):
                 ("M", C.c_int), ("eps", C.c_float), ("bm", C.c_int),
                 ("npass2", C.c_int), ("ldo", C.c_int), ("vt", C.c_void_p), ("S", C.c_int), ("ldt", C.c_int),
                 ("gx", C.c_void_p), ("gx_f32", C.c_int), ("gn_partial", C.c_void_p), ("gn_nchunk", C.c_int),
-                ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float)]
+                ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float),
+                ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int)]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -97,6 +99,9 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdmi_op_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "sdmi_op_groupnorm_acc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "sdmi_op_gemm_stat_layout": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sdmi_op_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "sdmi_gemm_config_dims": (None, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -416,9 +416,12 @@ int launch(const AttnArgs& a, hipStream_t st) {
   int dev = 0;
   SDMI_CHECK_HIP(hipGetDevice(&dev));
   SDMI_REQUIRE(dev >= 0 && dev < 16, "attention: device index %d out of range", dev);
-  // ring depth 3 where the LDS allows it at the occupancy the form is built for: d = 40 (two 8-wave workgroups per CU: 78 KB
-  // each) and d = 80 split (one workgroup per CU either way); d = 160 split fills the LDS with two stages.  SDMI_ATTN_NB=2: A/B
-  static const bool nb3 = !(getenv("SDMI_ATTN_NB") && atoi(getenv("SDMI_ATTN_NB")) == 2);
+  // ring depth 3 fits where the LDS allows it at the occupancy the form is built for: d = 40 (two 8-wave workgroups per CU:
+  // 78 KB each) and d = 80 split (one workgroup per CU either way); d = 160 split fills the LDS with two stages.  Measured
+  // (round 4, one MI355X, back-to-back launches): S = 4096 d = 40 78.0 us against 77.1 with two stages, S = 1024 d = 80 16.1
+  // against 15.0, whole step 3.992 vs 3.994 ms -- the K/V tiles are L2-resident and already land under the previous tile's
+  // MFMAs, a third stage only costs LDS.  So two stages stay the default; SDMI_ATTN_NB=3 selects the deeper ring.
+  static const bool nb3 = getenv("SDMI_ATTN_NB") && atoi(getenv("SDMI_ATTN_NB")) == 3;
   constexpr bool CAN3 = 3 * 2 * C::STAGE + C::EXTRA <= (D == 40 ? 80 * 1024 : 160 * 1024);
   if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + C::EXTRA));

@@ -61,7 +61,10 @@ __device__ unsigned long long g_b2b_clk[2][8];   // diagnostic build: shader-clo
 #define B2B_STAMP(role, i) do { } while (0)
 #endif
 
-template <class Cf>
+// GACC: the launch also accumulates the GroupNorm statistics of its output (B2bArgs::gacc; the feed-forward form, whose output
+// is the block's result).  A template parameter, not a run-time flag: the kernel sits at the 168-register limit of three waves
+// per SIMD and the other forms must not pay for the eight extra accumulators.
+template <class Cf, bool GACC>
 __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
   sdmi_kernarg_warm<sizeof(B2bArgs)>();
   constexpr int kBM = Cf::kBM, kMW = Cf::kMW, kNR = Cf::kNR, kAStage = Cf::kAStage, kCsBytes = Cf::kCsBytes;
@@ -80,6 +83,9 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
   if (wave_id >= kMW) {
     // =============================== DMA + epilogue waves ===============================
     const int dw = wave_id - kMW;
+    // the lane index from the execution mask (v_mbcnt), not from threadIdx: otherwise the thread-id register stays live -- and,
+    // at the 168-register limit, is spilled -- across the whole MFMA path (the two paths join behind their last barrier)
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int a_row = (dw * 64 + lane) >> 3, a_pc = lane & 7;
     const f16* a_src = p.a1 + (size_t)(m0 + (a_row < kBM ? a_row : 0)) * p.lda1 + ((a_pc ^ ((a_row >> 1) & 7)) * 8);
     // one K-step = (first product only) the 64x64 A1 tile + the 320x64 weight tile, 16 B per lane per instruction
@@ -425,19 +431,26 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
       } else {
         const float cs = (p.npass2 == 1 || pass == 0) ? p.cscale : 0.f;
         const size_t cofs = (size_t)pass * kC;
+        // GroupNorm statistics of the output (GnRec, common.h): this lane's two column quads stay the same over its rows.  Taken
+        // from the fp16 values with the packed dot product (one v_dot2_f32_f16 per pair and moment, as the row statistics
+        // above); a quad starts at a multiple of 4 and an atom is even, so a PAIR never straddles two atoms: the first pair of
+        // a quad always belongs to the quad's first atom, the second pair to it or to the next (decided once, at the end)
+        constexpr bool gstat = GACC;
+        constexpr int HB2 = GACC ? 2 : 4;          // rows per batch of this epilogue (GACC: two, the statistics need the registers)
+        float gq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // per quad {sum pair 0, sumsq pair 0, sum pair 1, sumsq pair 1}
 #pragma unroll
-        for (int hb = 0; hb < kNR; hb += 4) {
-          f32x4 cv[4][2];
+        for (int hb = 0; hb < kNR; hb += HB2) {
+          f32x4 cv[HB2][2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < HB2; ++i) {
             cv[i][0] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs0);
             cv[i][1] = *(const f32x4*)(Cs + (dw + 8 * (hb + i)) * kCsLd + cs1);
           }
-          f16x4 o[4][2];
+          f16x4 o[HB2][2];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < HB2; ++i)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 float v = cv[i][q][e] + bv[q][e];
@@ -446,9 +459,19 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
                 cv[i][q][e] = v;
                 o[i][q][e] = (f16)v;
               }
+              if constexpr (gstat) {
+                const f16x2 ones = f16x2{(f16)1.f, (f16)1.f};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                  const f16x2 x2 = f16x2{o[i][q][2 * h2], o[i][q][2 * h2 + 1]};     // (lanes beyond the 40 owners accumulate junk they never publish)
+                  gq[q][2 * h2] = __builtin_amdgcn_fdot2(x2, ones, gq[q][2 * h2], false);
+                  gq[q][2 * h2 + 1] = __builtin_amdgcn_fdot2(x2, x2, gq[q][2 * h2 + 1], false);
+                }
+              }
+            }
           if (own) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < HB2; ++i) {
               const size_t mo = (size_t)(m0 + dw + 8 * (hb + i)) * p.ldo + cofs;
               if (p.out_f32) {
                 *(f32x4*)((float*)p.out + mo + c0) = cv[i][0];
@@ -459,6 +482,44 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
                 *(f16x4*)((f16*)p.out + mo + c1) = o[i][1];
               }
             }
+          }
+        }
+        if constexpr (gstat) {
+          // one record per (DMA wave, quad) behind the fp32 tile (the ring is idle: every tile of the last product has been
+          // multiplied), then lanes 0..31 of the first DMA wave add up the quads of one 10-channel atom each over the 8 waves
+          // in a fixed order (fp64) and store them as this tile's record
+          float* s_q = (float*)(smem + kCsBytes + 2 * kBM * 4 + 256);
+          if (own) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int n = q ? c1 : c0;
+              const bool both = (gnrec_div_atom(p.gacc, n) + 1) * p.gacc.atom - n >= 4;      // the quad lies inside one atom
+              // record = {first atom: sum, sumsq; second atom: sum, sumsq}
+              *(f32x4*)(s_q + (dw * 80 + q * 40 + lane) * 4) =
+                  both ? f32x4{gq[q][0] + gq[q][2], gq[q][1] + gq[q][3], 0.f, 0.f} : f32x4{gq[q][0], gq[q][1], gq[q][2], gq[q][3]};
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS only: __syncthreads() would wait for the output stores to retire)
+          __builtin_amdgcn_s_barrier();                    // B8 (statistics only)
+          const int atom = p.gacc.atom;
+          if (dw == 0 && lane < p.gacc.natoms) {
+            const int at = lane;
+            const int q_lo = (at * atom) >> 2, q_hi = ((at + 1) * atom - 1) >> 2;     // the (at most 6) quads of the atom
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq) {
+              const int qd = min(q_lo + qq, q_hi);
+              const bool use = q_lo + qq <= q_hi;
+              const int sel = (gnrec_div_atom(p.gacc, 4 * qd) == at) ? 0 : 2;
+              f32x2 t[kDW];
+#pragma unroll
+              for (int w = 0; w < kDW; ++w) t[w] = *(const f32x2*)(s_q + (w * 80 + qd) * 4 + sel);
+#pragma unroll
+              for (int w = 0; w < kDW; ++w) { s1 += use ? t[w][0] : 0.f; s2 += use ? t[w][1] : 0.f; }
+            }
+            const int img = gnrec_div_rows(p.gacc, m0);
+            const int t_row = (m0 - img * p.gacc.rows_img) / kBM;       // this workgroup's record row (parts = 1)
+            ((f32x2*)p.gacc.rec)[(size_t)(img * p.gacc.T + t_row) * p.gacc.natoms + at] = f32x2{s1, s2};
           }
         }
       }
@@ -552,6 +613,7 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
       __syncthreads();                                   // B6
       if (pass + 1 < p.npass2) __syncthreads();          // B7
     }
+    if constexpr (GACC) __builtin_amdgcn_s_barrier();    // B8 (statistics only)
     B2B_STAMP(0, 6);
   }
 }
@@ -564,10 +626,19 @@ int launch_b2b(const B2bArgs& a, hipStream_t st) {
   SDMI_CHECK_HIP(hipGetDevice(&dev));
   SDMI_REQUIRE(dev >= 0 && dev < 16, "b2b: device index %d out of range", dev);
   if (!attr_done[dev]) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
+    if constexpr (BM == 32)
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL(b2b_kernel<Cf>, dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
+  if constexpr (BM == 32) {       // (the statistics form exists for 32-row tiles only: sdmi_launch_b2b)
+    if (a.gacc.rec) {
+      hipLaunchKernelGGL((b2b_kernel<Cf, true>), dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
+      SDMI_CHECK_HIP(hipGetLastError());
+      return SDMI_OK;
+    }
+  }
+  hipLaunchKernelGGL((b2b_kernel<Cf, false>), dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
@@ -582,7 +653,9 @@ extern "C" int sdmi_dbg_read_b2b(unsigned long long* host) {
 
 // bm: 32 or 64 rows per workgroup; 0 = 32 while that is at most one workgroup per CU (the 64x64 level: 256 of them; measured
 // 15.6 / 19.1 us against 18.9 / 22.1 us with 64 rows at M = 8192, but 39.5 / 49.7 against 36.1 / 44.3 us at M = 18432)
-int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm) {
+int sdmi_launch_b2b(const B2bArgs& a_in, hipStream_t st, int bm) {
+  B2bArgs a = a_in;
+  gnrec_magic(a.gacc);
   SDMI_REQUIRE(a.M > 0 && a.M % 32 == 0, "b2b: M=%d must be a positive multiple of 32", a.M);
   SDMI_REQUIRE(a.K2 == kC || (a.K2 == 2 * kC && a.partial), "b2b: K2=%d (C = %d: K2 = C, or 2C with the partial fold)", a.K2, kC);
   SDMI_REQUIRE(!a.partial || a.K2 == 2 * kC, "b2b: the partial fold needs K2 = 2C");
@@ -593,9 +666,13 @@ int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm) {
                                  a.ldt >= a.S && a.ldt % 8 == 0),
                "b2b: the three-pass form (q | k | v) needs fp16 outputs, no residual, a V^T target and S %% 32 == 0");
   SDMI_REQUIRE(a.ldo >= a.npass2 * kC - (a.npass2 == 3 ? kC : 0) && a.ldo % 8 == 0, "b2b: output row stride %d", a.ldo);
+  SDMI_REQUIRE(!a.gacc.rec || (a.npass2 == 1 && a.gacc.atom >= 4 && a.gacc.atom <= 16 && a.gacc.atom % 2 == 0 && a.gacc.natoms * a.gacc.atom == kC && a.gacc.natoms <= 32 &&
+                               a.gacc.rows_img % 32 == 0 && a.M % a.gacc.rows_img == 0 && a.gacc.parts == 1 && a.gacc.T == a.gacc.rows_img / 32),
+               "b2b: GroupNorm statistics need the one-pass form, even atoms that tile the 320 columns, whole 32-row tiles per image and T = rows / 32, parts = 1");
   if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256 || (a.npass2 == 3 && a.S % 64 != 0)) ? 32 : 64;
   if (a.gx && a.S % 64 != 0) bm = 32;
   SDMI_REQUIRE((a.npass2 == 1 && !a.gx) || a.S % bm == 0, "b2b: a %d-row tile would straddle images of %d tokens", bm, a.S);
   SDMI_REQUIRE((bm == 32 || bm == 64) && a.M % bm == 0, "b2b: tile height %d does not divide M=%d", bm, a.M);
+  SDMI_REQUIRE(!a.gacc.rec || bm == 32, "b2b: GroupNorm statistics are taken by the 32-row form only (M=%d)", a.M);
   return bm == 32 ? launch_b2b<32>(a, st) : launch_b2b<64>(a, st);
 }

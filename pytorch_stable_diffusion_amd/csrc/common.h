@@ -36,6 +36,99 @@ __device__ __forceinline__ void sdmi_kernarg_warm() {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics taken from the PRODUCER's epilogue (sd/diffusion.py:173,199,294,733: every GroupNorm input is the
+// output of a conv / linear of this library).  The kernel that writes a tensor also leaves, per image, per block of rows it
+// owns ("record row" t) and per ATOM of `atom` consecutive channels (10 in the UNet: every group of every GroupNorm that reads
+// the tensor -- alone or as one half of a skip concat, 10 / 20 / 30 / 40 / 60 / 80 channels per group -- is a whole number of
+// atoms), the moments {sum x, sum x^2} of what it stored; the GroupNorm is then ONE normalising pass whose workgroups add up the
+// records of their own groups in a fixed order (fp64), and the statistics launch (a full extra read of the tensor) is gone.
+// Plain stores, no atomics: every (record row, atom, part) slot is written by exactly one workgroup, so nothing has to be
+// zeroed and the result does not depend on the order of the workgroups.  (A first version accumulated 64-bit fixed-point
+// integers with atomics: 4 x atoms x workgroups of them on a few KB cost 2 - 10 us per producer launch: 235 vs 252 steps/s.)
+// Layout: rec[((image * T + t) * natoms + atom) * parts + part] = {sum, sum of squares} (float2).  parts = 2 for tiled
+// producers: an atom that straddles two column tiles gets its first channels' moments from the left tile (part 0) and the
+// rest from the right one (part 1); a tile that holds the whole atom writes {moments, 0}.
+struct GnRec {
+  float* rec;          // nullptr: off
+  int atom;            // channels per atom; the tensor has natoms = C / atom of them
+  int natoms;
+  int rows_img;        // rows (pixels) of one image inside a block of `mod` rows; a producer's row block never straddles images
+  int mod;             // M, or M / 4 for the phase-decomposed upsample conv (rows are phase-major there)
+  int T;               // record rows per image
+  int parts;           // 1 or 2
+  // filled by the launchers (gnrec_magic): exact fixed-point reciprocals, so that no integer division by a run-time value is
+  // left in the epilogues (each is ~40 instructions of one wave; a dozen of them were most of the 1.2 us a first version of the
+  // statistics added to every producer launch):  x / atom == (x * atom_magic) >> 20 for x < 40000,
+  // m / rows_img == (m * rows_magic) >> 36 for m * rows_img < 2^36
+  unsigned atom_magic;
+  unsigned long long rows_magic;
+};
+inline void gnrec_magic(GnRec& g) {
+  if (!g.rec || g.atom <= 0 || g.rows_img <= 0) return;
+  g.atom_magic = (1u << 20) / (unsigned)g.atom + 1u;
+  g.rows_magic = (1ull << 36) / (unsigned long long)g.rows_img + 1ull;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int gnrec_div_atom(const GnRec& g, int x) { return (int)(((unsigned)x * g.atom_magic) >> 20); }
+__device__ __forceinline__ int gnrec_div_rows(const GnRec& g, int m) { return (int)(((unsigned long long)m * g.rows_magic) >> 36); }
+// sum over the lanes l ^ O of a wave, O in {8, 16, 32}, on the VALU (DPP row rotate / v_permlane16_swap / v_permlane32_swap)
+// instead of ds_bpermute round trips: swapping a register with a copy of itself leaves {even rows, even rows} in one result
+// and {odd, odd} in the other (rows of 16 lanes; halves of 32 for permlane32), so their sum is the xor-partner sum in every lane
+template <int O>
+__device__ __forceinline__ float wave_xor_sum(float x) {
+  static_assert(O == 8 || O == 16 || O == 32, "lane distance");
+  const unsigned u = __float_as_uint(x);
+  if constexpr (O == 8) {
+    return x + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  } else if constexpr (O == 16) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  } else {
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+}
+// Per-thread side: a thread stores 8 consecutive columns n .. n+7 of several rows and keeps their moments per COLUMN (one add
+// and one fma per element; a first version split them into the two atoms per element -- four selects and four adds more -- and
+// cost the large-map GEMMs ~1.5 us each); the columns are dealt to the (at most two) atoms they fall into once, at the end:
+// the first `split` columns to atom n / atom, the rest to the next one.
+template <bool PERCOL = true>
+struct GaccThread {
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  __device__ __forceinline__ void add(const float (&x)[8], int) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] += x[e]; q[e] = fmaf(x[e], x[e], q[e]); }
+  }
+  // {first atom: sum, sumsq; second atom: sum, sumsq}
+  __device__ __forceinline__ f32x4 parts(int split) const {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool a = e < split;
+      r[0] += a ? s[e] : 0.f; r[1] += a ? q[e] : 0.f;
+      r[2] += a ? 0.f : s[e]; r[3] += a ? 0.f : q[e];
+    }
+    return r;
+  }
+};
+// the 1024-thread GEMM kernels have 128 registers per lane and one to four items per thread: four accumulators, the columns
+// dealt to the two atoms as they are added
+template <>
+struct GaccThread<false> {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  __device__ __forceinline__ void add(const float (&x)[8], int split) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool a = e < split;
+      r[0] += a ? x[e] : 0.f; r[1] += a ? x[e] * x[e] : 0.f;
+      r[2] += a ? 0.f : x[e]; r[3] += a ? 0.f : x[e] * x[e];
+    }
+  }
+  __device__ __forceinline__ f32x4 parts(int) const { return r; }
+};
+#endif
+
 #define SDMI_OK 0
 #define SDMI_EINVAL (-22)
 #define SDMI_ENOMEM (-12)
@@ -143,7 +236,12 @@ struct GemmArgs {
   // applies  rstd (sum of folded slabs - mean g) + sum of plain slabs + bias (+ res)
   float* ln_out;
   int no_finalize;     // split-K: leave the partial sums in the slabs, launch no splitk_finalize
+  // GroupNorm statistics of the output from this launch's epilogue (GnRec above): the one-pass path accumulates them in
+  // store_tile, a split-K launch in splitk_finalize.  Needs rows_img % BM == 0 (a tile inside one image), no transposed tail.
+  GnRec gacc;
 };
+// can the one-pass epilogue of tile config `cfg` accumulate the GroupNorm statistics of this GEMM? (gemm.hip)
+bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg);
 
 // cfg < 0: heuristic.  ksplit_out / ksteps_per_out: effective split-K factor and K-steps per slice of the launch.
 // a.no_finalize = 1: a split-K launch only writes its slabs; the caller combines them (sdmi_launch_splitk_finalize with
@@ -175,6 +273,7 @@ struct B2bArgs {
   // images of S rows); a1 is unused.
   const void* gx; int gx_f32;
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
+  GnRec gacc;                     // GroupNorm statistics of `out` (npass2 == 1 only; rows_img = pixels per image, mod = M, T = rows_img / 32, parts = 1)
 };
 int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M
 int sdmi_gemm_num_cfgs();
@@ -219,6 +318,9 @@ struct GnArgs {
   // the finalize launch of a split-K conv and the GroupNorm that follows it (sd/diffusion.py:179 -> 199) as ONE kernel.
   // sout / sout16 (optional) receive x itself (fp32 / fp16 [B*P][C]) when another consumer needs the conv's output.
   const float* slab; int ksplit; const float* sbias; const void* sres; int sres_f32; float* sout; f16* sout16;
+  // acc0 != nullptr: the statistics come from the producers' epilogues (GnRec: acc0 for x0's C0 channels, acc1 for x1's, with
+  // their own record rows T and parts), atoms of `atom` channels; one normalising pass, no statistics launch
+  const float* acc0; const float* acc1; int atom; int accT0, accT1, accP0, accP1;
 };
 int sdmi_gn_nchunk(int P);
 int sdmi_gn_launches(const GnArgs& a);
@@ -272,3 +374,8 @@ int sdmi_launch_xattn_mask(const f16* k, const f16* v, f16* dk, f16* dv, int B, 
                            hipStream_t st);
 int sdmi_launch_pack_ups_phase(const void* w, int w_f32, f16* out, int O, int I, hipStream_t st);
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);
+// can the split-K combine take GroupNorm statistics for this shape?  T_out: record rows per image it will write (parts = 1)
+bool sdmi_finalize_gacc_ok(const GemmArgs& a, int* T_out = nullptr);
+// record rows per image (GnRec::T) / parts the one-pass epilogue of tile config `cfg` writes
+int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg);
+int sdmi_gemm_pick_cfg(const GemmArgs& a);       // the heuristic tile (cfg < 0)

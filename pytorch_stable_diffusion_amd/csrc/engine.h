@@ -70,8 +70,16 @@ struct Act {
   f16* h = nullptr;
   float* f = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
+  // GroupNorm statistics of this tensor, left behind by the kernel that wrote it (GnRec, common.h): grec = its records
+  // (room for kGnRecMax float2 per image), gT / gparts = record rows per image and parts as that producer wrote them,
+  // gok = the producer really did
+  float* grec = nullptr;
+  int gT = 0, gparts = 0;
+  bool gok = false;
   int M() const { return B * H * W; }
 };
+constexpr int kGnAtom = 10;     // every GroupNorm group of the UNet (10 .. 80 channels) is a whole number of 10-channel atoms
+constexpr int kGnRecMax = 4096; // records (T x atoms x parts) per image a producer may write (gemm.hip kGaccMaxRec)
 
 struct Arena {
   char* base = nullptr;
@@ -223,6 +231,20 @@ struct Engine {
   Arena arena;
   float* slab = nullptr; size_t slab_bytes = 0;
   float* gn_partial = nullptr;
+  // producer-side GroupNorm statistics (GnRec): the records live in the activation arena next to the tensor they describe
+  bool gacc_enabled = false;           // the UNet engine turns it on (the VAE / CLIP engines take every GroupNorm's own statistics)
+  static bool gacc_on() { static const bool on = !(getenv("SDMI_GN_ACC") && atoi(getenv("SDMI_GN_ACC")) == 0); return on; }
+  static int gacc_min_px() { static const int v = getenv("SDMI_GN_ACC_MINPX") ? atoi(getenv("SDMI_GN_ACC_MINPX")) : 1024; return v; }
+  void attach_gacc(Act* a) {
+    a->grec = nullptr; a->gok = false; a->gT = a->gparts = 0;
+    if (!gacc_enabled || !gacc_on() || a->C % (32 * kGnAtom) != 0 || a->H * a->W < gacc_min_px()) return;
+    a->grec = (float*)arena.alloc((size_t)a->B * kGnRecMax * 8);       // (none left: the GroupNorm takes its own statistics)
+  }
+  static void set_gacc(GemmArgs& a, const Act& y) {
+    a.gacc.rec = y.grec; a.gacc.atom = kGnAtom; a.gacc.natoms = y.C / kGnAtom;
+    a.gacc.rows_img = a.phase2 ? a.Hs * a.Ws : a.Ho * a.Wo;
+    a.gacc.mod = a.phase2 ? a.M / 4 : a.M;
+  }
   float* eps_buf = nullptr; size_t eps_elems = 0;
   std::map<ShapeKey, Plan> plans;
   int tuned_shapes = 0;       // shapes this handle had to time itself (not found in the plan store)
@@ -557,6 +579,8 @@ struct Engine {
     a->f = nullptr;
     if (is_stream && stream_f32) a->f = (float*)arena.alloc(n * 4);
     if (!a->h || (is_stream && stream_f32 && !a->f)) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
+    a->grec = nullptr; a->gok = false; a->gT = a->gparts = 0;
+    if (is_stream) attach_gacc(a);
     return SDMI_OK;
   }
 
@@ -603,7 +627,9 @@ struct Engine {
   }
 
   // defer: a split-K launch leaves its partial sums in the slabs for the GroupNorm that follows (see `pend`)
-  int gemm(GemmArgs a, RowStat* rs = nullptr, bool defer = false) {
+  // yact: the output tensor; when it carries an accumulator (Act::gacc) the launch also takes the GroupNorm statistics of
+  // what it writes -- in the one-pass epilogue or in the split-K combine -- if the plan's tile allows it (yact->gok says so)
+  int gemm(GemmArgs a, RowStat* rs = nullptr, bool defer = false, Act* yact = nullptr) {
     TRY(flush_pending());
     std::map<ShapeKey, Plan>::iterator it;
     TRY(plan_of(a, &it));
@@ -611,6 +637,14 @@ struct Engine {
     defer = defer && defer_on() && a.ksplit > 1 && !a.outT && !a.act && !a.phase2 && a.cs_hi == 0 && !a.ln_stat && !a.rowstat &&
             a.ldc == a.N && (!a.res || a.ldr == a.N) && a.Ho * a.Wo <= defer_max_px();
     a.no_finalize = 1;                     // the combine is this function's own launch (timed as its own class) or deferred
+    memset(&a.gacc, 0, sizeof(a.gacc));
+    if (yact && yact->grec && !defer && it->second.cfg >= 0) {
+      set_gacc(a, *yact);
+      bool ok;
+      if (a.ksplit > 1) { a.gacc.parts = 1; ok = sdmi_finalize_gacc_ok(a, &a.gacc.T); }
+      else { a.gacc.parts = 2; ok = sdmi_gemm_gacc_ok(a, it->second.cfg); if (ok) a.gacc.T = sdmi_gemm_gacc_T(a, it->second.cfg); }
+      if (!ok) memset(&a.gacc, 0, sizeof(a.gacc));
+    }
     if (rs) {
       static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
       rs->ptr = nullptr;
@@ -631,6 +665,11 @@ struct Engine {
     TRY(sdmi_launch_gemm(a, it->second.cfg, st, &ks_eff, &kper));
     prof_end();
     const bool deferred = defer && ks_eff > 1;
+    // (the launcher may lower the split-K factor: statistics taken by the combine need ks_eff > 1, by the epilogue == 1)
+    if (yact) {
+      yact->gok = a.gacc.rec != nullptr && (a.ksplit > 1) == (ks_eff > 1) && (ks_eff <= 1 || ks_eff == a.ksplit);
+      yact->gT = a.gacc.T; yact->gparts = a.gacc.parts;
+    }
     if (ks_eff > 1) {
       GemmArgs f = a;
       f.ksplit = ks_eff; f.no_finalize = 0;
@@ -764,6 +803,12 @@ struct Engine {
     g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
     g.y = y->h; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
     // x is the output of a split-K conv that has not been combined yet: combine + normalise in one launch
+    // statistics already taken by the producers' epilogues: one normalising pass (maps the single-launch kernel handles in
+    // 64 workgroups keep it below gacc_min_px: attach_gacc)
+    if (x.gok && x.grec && (!x1 || (x1->gok && x1->grec)) && !pend) {
+      g.acc0 = x.grec; g.accT0 = x.gT; g.accP0 = x.gparts; g.atom = kGnAtom;
+      if (x1) { g.acc1 = x1->grec; g.accT1 = x1->gT; g.accP1 = x1->gparts; }
+    }
     const bool from_slab = pend && !x1 && pend_key == (f32 ? (const void*)x.f : (const void*)x.h) && sdmi_gn_launches(g) == 1 &&
                            pend_args.M == x.B * g.P && pend_args.N == C;
     if (from_slab) {
@@ -779,7 +824,8 @@ struct Engine {
     TRY(sdmi_launch_groupnorm(g, st));
     prof_end();
     launches += sdmi_gn_launches(g);
-    if (from_slab) log_launch("gn_fused_slab C=%d P=%d B=%d silu=%d split=%d", C, g.P, g.B, silu, g.ksplit);
+    if (g.acc0) log_launch("gn_apply_acc C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu);
+    else if (from_slab) log_launch("gn_fused_slab C=%d P=%d B=%d silu=%d split=%d", C, g.P, g.B, silu, g.ksplit);
     else if (sdmi_gn_launches(g) == 1) log_launch("gn_fused C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu);
     else { log_launch("gn_stats C=%d P=%d B=%d", C, g.P, g.B); log_launch("gn_apply C=%d P=%d B=%d silu=%d", C, g.P, g.B, silu); }
     return SDMI_OK;
@@ -834,7 +880,8 @@ struct Engine {
       GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
       a.bias = bias1; a.out = h.h; a.ldc = h.C;
       pend_keep16 = false;                     // h has one reader: groupnorm_merged
-      TRY(gemm(a, nullptr, /*defer=*/true));
+      attach_gacc(&h);
+      TRY(gemm(a, nullptr, /*defer=*/true, &h));
     }
     TRY(new_act(x.B, x.H, x.W, r.cout, true, y));
     if (r.has_skip && !r.w2s) {
@@ -858,7 +905,7 @@ struct Engine {
     }
     set_out(a, *y);
     pend_keep16 = true;
-    TRY(gemm(a, nullptr, /*defer=*/y_to_gn));
+    TRY(gemm(a, nullptr, /*defer=*/y_to_gn, y));
     return SDMI_OK;
   }
 
@@ -890,7 +937,7 @@ struct Engine {
 
   // out_proj + residual, then the next Linear with its LayerNorm, as one launch (b2b.hip): C = 320 blocks only
   int b2b(const Act& a1, const ConvW& w1, const Act& r1, const Act* s_out, const FoldW& f2, int K2, int partial, float cscale,
-          const Act* r2, const Act& y) {
+          const Act* r2, const Act& y, Act* y_gacc = nullptr) {
     TRY(flush_pending());
     B2bArgs t;
     memset(&t, 0, sizeof(t));
@@ -901,6 +948,12 @@ struct Engine {
     if (r2) { if (r2->f) { t.r2 = r2->f; t.r2_f32 = 1; } else { t.r2 = r2->h; } }
     if (y.f) { t.out = y.f; t.out_f32 = 1; t.out16 = y.h; } else { t.out = y.h; }
     t.M = a1.M(); t.eps = 1e-5f; t.npass2 = 1; t.ldo = 320;
+    if (y_gacc && y_gacc->grec && (a1.H * a1.W) % 64 == 0 && t.M / 32 <= 256 &&      // (32-row tiles only: the 64-row form has no registers to spare)
+        (a1.H * a1.W) / 32 * (320 / kGnAtom) <= kGnRecMax) {
+      t.gacc.rec = y_gacc->grec; t.gacc.atom = kGnAtom; t.gacc.natoms = 320 / kGnAtom; t.gacc.rows_img = a1.H * a1.W; t.gacc.mod = t.M;
+      t.gacc.T = t.gacc.rows_img / 32; t.gacc.parts = 1;
+      y_gacc->gok = true; y_gacc->gT = t.gacc.T; y_gacc->gparts = 1;
+    }
     const double flops = 2.0 * t.M * 320.0 * (320.0 + K2);
     prof_begin(0, flops);
     TRY(sdmi_launch_b2b(t, st));
@@ -1063,7 +1116,7 @@ struct Engine {
       if (use_b2b) {
         // s2 = out_proj 2 + s1 never leaves the workgroup: its only reader is the feed-forward
         TRY(new_act(B, x.H, x.W, C, true, y));
-        TRY(b2b(ao, w.out2, s1, nullptr, w.ffn_f, 2 * C, 1, 0.f, &x, *y));
+        TRY(b2b(ao, w.out2, s1, nullptr, w.ffn_f, 2 * C, 1, 0.f, &x, *y, y));
         return SDMI_OK;
       }
       { GemmArgs a = base_args(ao, nullptr, w.out2, x.H, x.W, 1, 0); set_res(a, s1); set_out(a, s2); TRY(gemm(a, &rs)); }
@@ -1081,7 +1134,7 @@ struct Engine {
       }
       set_res(a, x);
       set_out(a, *y);
-      TRY(gemm(a));
+      TRY(gemm(a, nullptr, false, y));
     }
     return SDMI_OK;
   }
@@ -1104,13 +1157,13 @@ struct Engine {
       GemmArgs a = base_args(x, nullptr, wp, x.H, x.W, 1, 0);
       a.img_rows = a.M; a.w_img_stride = w.O * 4 * x.C; a.M *= 4; a.phase2 = 1;
       set_out(a, *y);
-      TRY(gemm(a));
+      TRY(gemm(a, nullptr, false, y));
       return SDMI_OK;
     }
     GemmArgs a = base_args(x, nullptr, w, Ho, Wo, stride, ups);
     a.pad = pad;
     set_out(a, *y);
-    TRY(gemm(a));
+    TRY(gemm(a, nullptr, false, y));
     return SDMI_OK;
   }
 

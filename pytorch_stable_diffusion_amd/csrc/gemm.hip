@@ -18,6 +18,10 @@
 //   * split-K over gridDim.y writes fp32 slabs combined by splitk_finalize (small-M layers).
 #include "common.h"
 
+#ifndef SDMI_GACC_ABLATE
+#define SDMI_GACC_ABLATE 0      // diagnostic builds: 1 = no flush at all, 2 = flush without the record stores, 4 = no per-item accumulation
+#endif
+
 namespace {
 
 template <int BM_, int BN_, int WM_, int WN_, int NS_, int STG_ = 0, int KPI_ = 1, int PW_ = 1>
@@ -103,6 +107,16 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
   }
 
   const bool transposed = p.outT != nullptr && n0 >= p.nt0;
+  // GroupNorm statistics of the stored values (GnRec, common.h): with NT a multiple of the BN/8 column chunks of a row, a thread
+  // keeps the SAME 8 columns in every item, so it accumulates their moments in four registers (the two atoms they fall into)
+  constexpr bool GACC = (NT % (BN / 8) == 0) && (BN % 64 == 0);
+  const bool gstat = GACC && p.gacc.rec != nullptr;      // workgroup-uniform
+  GaccThread<(NT < 1024)> gth;
+  int g_split = 8;
+  if (gstat) {
+    const int n = n0 + (tid % (BN / 8)) * 8;
+    g_split = min(8, (gnrec_div_atom(p.gacc, n) + 1) * p.gacc.atom - n);
+  }
   if (!transposed) {
     // Phase 1 issues EVERY residual / bias load of this thread's items before anything consumes them, so the tile
     // pays one memory latency instead of one per item (a one-K-step workgroup used to live 14 K cycles, most of
@@ -220,6 +234,12 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float x = (float)o16[e]; rs += x; rq += x * x; }
+        if (gstat) {       // moments of what the GroupNorm will read: the fp32 stream where there is one, else the fp16 tensor
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = p.out_f32 ? v[e] : (float)o16[e];
+          if (!(SDMI_GACC_ABLATE & 4)) gth.add(x, g_split);
+        }
       }
       if (p.rowstat && ((BN / 8) & (BN / 8 - 1)) == 0) {   // wave-uniform branch; the BN/8 lanes of one row are consecutive and aligned (power-of-two tiles only)
 #pragma unroll
@@ -228,6 +248,67 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       }
     }
     }   // chunk
+    if constexpr (GACC) {
+      if (gstat && !(SDMI_GACC_ABLATE & 1)) {
+        // fixed-order reduction inside the workgroup: lanes of a wave that hold the same column chunk (butterfly), one record
+        // per (wave, chunk) in LDS, then one thread per atom of the tile adds its chunks' records over the waves in fp64 and
+        // stores the atom's moments into this tile's record (common.h GnRec)
+        constexpr int CH8 = BN / 8, NWV = NT / 64;
+        static_assert(NWV * CH8 * 16 <= BM * BN * 4, "the records fit the fp32 tile they replace");
+        // the records go where the fp32 tile was (every thread has read its items: barrier first); no LDS of their own -- the
+        // halo kernels run with all 160 KiB of dynamic LDS
+        // (raw barriers with an LDS-only wait: __syncthreads() also waits for vmcnt(0), i.e. for every output store of the
+        // epilogue to RETIRE -- measured 1.2 us per launch, all of what the statistics cost)
+        float* s_g = const_cast<float*>(Cs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const f32x4 mine = gth.parts(g_split);
+        float qa = mine[0], qb = mine[1], qc = mine[2], qd = mine[3];
+        if constexpr (CH8 <= 8) { qa = wave_xor_sum<8>(qa); qb = wave_xor_sum<8>(qb); qc = wave_xor_sum<8>(qc); qd = wave_xor_sum<8>(qd); }
+        if constexpr (CH8 <= 16) { qa = wave_xor_sum<16>(qa); qb = wave_xor_sum<16>(qb); qc = wave_xor_sum<16>(qc); qd = wave_xor_sum<16>(qd); }
+        qa = wave_xor_sum<32>(qa); qb = wave_xor_sum<32>(qb); qc = wave_xor_sum<32>(qc); qd = wave_xor_sum<32>(qd);
+        const int ln = tid & 63, wv = tid >> 6;
+        if (ln < CH8) *(f32x4*)(s_g + (wv * CH8 + ln) * 4) = f32x4{qa, qb, qc, qd};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // one lane per atom of the tile adds the (at most three) column chunks of the atom over the waves' records in a fixed
+        // order; fp32 like the per-thread sums below them (the GroupNorm adds the tiles' records up in fp64)
+        const int atom = p.gacc.atom;
+        const int a_first = gnrec_div_atom(p.gacc, n0), a_last = gnrec_div_atom(p.gacc, min(p.N, n0 + BN) - 1);
+        if (tid <= a_last - a_first) {
+          const int at = a_first + tid;
+          const int lo_col = max(at * atom, n0) - n0, hi_col = min((at + 1) * atom, n0 + BN) - 1 - n0;   // tile-local columns
+          const int c_lo = lo_col >> 3, c_hi = hi_col >> 3;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {                            // at most three chunks (atom <= 16 ... 2 x 8 + 2)
+            const int c = min(c_lo + cc, c_hi);
+            const bool use = c_lo + cc <= c_hi;
+            const int sel = (gnrec_div_atom(p.gacc, n0 + 8 * c) == at) ? 0 : 2;      // the chunk's first or second part belongs to this atom
+            f32x2 t[NWV];
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t[w] = *(const f32x2*)(s_g + (w * CH8 + c) * 4 + sel);
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { s1 += use ? t[w][0] : 0.f; s2 += use ? t[w][1] : 0.f; }
+          }
+          // record row of this tile: (phase,) image, row block inside the image
+          const bool phased = p.gacc.mod != p.M;
+          const int ph = phased ? m0 / p.gacc.mod : 0;
+          const int mm = m0 - ph * p.gacc.mod;
+          const int img = gnrec_div_rows(p.gacc, mm);
+          const int t_row = ph * (p.gacc.rows_img / BM) + (mm - img * p.gacc.rows_img) / BM;
+          f32x2* r = (f32x2*)p.gacc.rec + ((size_t)(img * p.gacc.T + t_row) * p.gacc.natoms + at) * 2;
+          // the tile that holds the atom's first channel writes part 0, the one that holds its last channel part 1 (zero
+          // when both are this tile): every slot is written exactly once per launch
+          const bool has_first = at * atom >= n0, has_last = (at + 1) * atom <= n0 + BN;
+          if (SDMI_GACC_ABLATE & 2) { asm volatile("" ::"v"(s1), "v"(s2), "v"(r)); }
+          else {
+            if (has_first) r[0] = f32x2{s1, s2};
+            if (has_last) r[1] = has_first ? f32x2{0.f, 0.f} : f32x2{s1, s2};
+          }
+        }
+      }
+    }
   } else {
     // transposed tail: 8 rows (tokens) of one column -> ONE 16-byte store along the key axis.  With the attention
     // kernel's quad-permuted key order (vt_pos: quads of a 16-key group stored as q0,q2,q1,q3) the 8 tokens a thread
@@ -1032,15 +1113,10 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #endif
 }
 
-// out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path)
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
-  sdmi_kernarg_warm<sizeof(GemmArgs)>();
-  const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
-  const unsigned n8 = (unsigned)(p.N / 8);
-  const size_t MN = (size_t)p.M * p.N;
-  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total8; idx += gridDim.x * 256u) {
-    const unsigned mq = idx / n8;
-    const int ms = (int)mq, n = (int)(idx - mq * n8) * 8;       // ms: slab row
+// out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path): one item = 8 columns n .. n+7 of slab row ms.
+// Returns true with the values the GroupNorm of this tensor will read in x (the non-transposed path only).
+__device__ __forceinline__ bool finalize_item(const GemmArgs& p, int ms, int n, size_t MN, float (&x)[8]) {
+  {
     const int m = out_row(p, ms);                               // output row (phase2 scatter; identity otherwise)
     float v[8], va[8];                 // va: slabs of the LayerNorm-folded K range (partial fold + split-K), v: the rest
 #pragma unroll
@@ -1109,7 +1185,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
       const int b = m / p.S, s = m - b * p.S;
 #pragma unroll
       for (int e = 0; e < 8; ++e) p.outT[((size_t)b * Ct + (n + e - p.nt0)) * p.ldt + vt_pos(s, p.tperm)] = (f16)v[e];
-      continue;
+      return false;
     }
     if (p.res) {
 #pragma unroll
@@ -1129,6 +1205,75 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     } else {
       *(f16x8*)((f16*)p.out + (size_t)m * p.ldc + n) = o16;
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p.out_f32 ? v[e] : (float)o16[e];
+    return true;
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
+  sdmi_kernarg_warm<sizeof(GemmArgs)>();
+  const unsigned total8 = (unsigned)p.M * (unsigned)(p.N / 8);      // < 2^31 (launcher): 32-bit index math, no 64-bit division
+  const unsigned n8 = (unsigned)(p.N / 8);
+  const size_t MN = (size_t)p.M * p.N;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total8; idx += gridDim.x * 256u) {
+    const unsigned mq = idx / n8;
+    float x[8];
+    (void)finalize_item(p, (int)mq, (int)(idx - mq * n8) * 8, MN, x);
+  }
+}
+
+// The same combine with the GroupNorm statistics of the result (GnRec, common.h) taken on the way: a workgroup of 320 threads
+// takes `rows_wg` consecutive rows of one image and one 320-column slice of them, thread t always column chunk t % 40, so the
+// moments of its 8 columns stay in four registers; one record per thread in LDS, then one thread per atom of the slice adds
+// its chunks' records in a fixed order (fp64) and stores them as this row block's record.
+constexpr int kFinNT = 320, kFinCols = 320;
+template <int NI>          // rows per workgroup = 8 NI: the NI items of a thread are unrolled, so their slab loads fly together
+__global__ __launch_bounds__(kFinNT) void splitk_finalize_gacc_kernel(GemmArgs p, int nsl) {
+  sdmi_kernarg_warm<sizeof(GemmArgs) + 8>();
+  __shared__ float s_g[kFinNT * 4];
+  const int tid = threadIdx.x;
+  constexpr int n8 = kFinCols / 8, rpp = kFinNT / n8;   // 40 column chunks, 8 rows per pass
+  constexpr int rows_wg = NI * rpp;
+  const int rb = blockIdx.x / nsl, cs = blockIdx.x - rb * nsl;
+  const int c8 = tid % n8, r0 = tid / n8;
+  const int n = cs * kFinCols + c8 * 8;
+  const size_t MN = (size_t)p.M * p.N;
+  const int row_base = rb * rows_wg;
+  const int atom = p.gacc.atom;
+  const int split = min(8, (gnrec_div_atom(p.gacc, n) + 1) * atom - n);
+  GaccThread<> gth;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int ms = row_base + r0 + i * rpp;      // < M: rows_wg divides the rows of an image (launcher)
+    float x[8];
+    if (finalize_item(p, ms, n, MN, x)) gth.add(x, split);
+  }
+  *(f32x4*)(s_g + tid * 4) = gth.parts(split);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (not __syncthreads(): its vmcnt(0) would wait for the output stores to retire)
+  __builtin_amdgcn_s_barrier();
+  const int aps = gnrec_div_atom(p.gacc, kFinCols);     // atoms per slice (the slice starts on an atom boundary)
+  if (tid < aps) {
+    const int lo_col = tid * atom, hi_col = (tid + 1) * atom - 1;      // slice-local columns
+    const int c_lo = lo_col >> 3, c_hi = hi_col >> 3;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const int c = min(c_lo + cc, c_hi);
+      const bool use = c_lo + cc <= c_hi;
+      const int sel = (gnrec_div_atom(p.gacc, 8 * c) == tid) ? 0 : 2;
+      f32x2 t[rpp];
+#pragma unroll
+      for (int k = 0; k < rpp; ++k) t[k] = *(const f32x2*)(s_g + (k * n8 + c) * 4 + sel);
+#pragma unroll
+      for (int k = 0; k < rpp; ++k) { s1 += use ? t[k][0] : 0.f; s2 += use ? t[k][1] : 0.f; }
+    }
+    const bool phased = p.gacc.mod != p.M;
+    const int ph = phased ? row_base / p.gacc.mod : 0;
+    const int mm = row_base - ph * p.gacc.mod;
+    const int img = gnrec_div_rows(p.gacc, mm);
+    const int t_row = ph * (p.gacc.rows_img / rows_wg) + (mm - img * p.gacc.rows_img) / rows_wg;
+    ((f32x2*)p.gacc.rec)[(size_t)(img * p.gacc.T + t_row) * p.gacc.natoms + cs * aps + tid] = f32x2{s1, s2};
   }
 }
 
@@ -1248,6 +1393,24 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   return true;
 }
 
+// Every GroupNorm workgroup adds up all T x natoms x parts records of its image (as it did the chunk partials of gn_stats): 32 KiB at most
+constexpr int kGaccMaxRec = 4096;          // T * natoms * parts: 16 loads per thread of the GroupNorm that adds them up (norm.hip gn_apply_kernel)
+static bool gacc_atom_ok(int atom) { return atom == 4 || (atom >= 8 && atom <= 16 && atom % 2 == 0); }   // an 8-column chunk spans <= 2 atoms, an atom <= 3 chunks, pairs never straddle
+
+// one-pass epilogue (store_tile) statistics: whole tiles inside one image, a tile shape whose threads keep their columns
+bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg) {
+  if (cfg < 0 || cfg >= sdmi_gemm_num_cfgs()) return false;
+  const CfgInfo& c = cfg_info(cfg);
+  if (a.outT || !gacc_atom_ok(a.gacc.atom) || a.gacc.natoms * a.gacc.atom != a.N || a.gacc.rows_img <= 0) return false;
+  if (c.BN % 64 != 0 || c.NT % (c.BN / 8) != 0 || c.BN / a.gacc.atom + 2 > c.NT) return false;   // one lane per atom of a tile
+  if (a.gacc.rows_img % c.BM != 0 || a.gacc.mod % a.gacc.rows_img != 0 || a.M % a.gacc.mod != 0) return false;
+  return (long)sdmi_gemm_gacc_T(a, cfg) * a.gacc.natoms * 2 <= kGaccMaxRec;
+}
+int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg) {
+  const CfgInfo& c = cfg_info(cfg);
+  return (a.M / a.gacc.mod) * (a.gacc.rows_img / c.BM);
+}
+
 static int pick_cfg(const GemmArgs& a) {
   // heuristic default (the UNet plan autotunes over all cfgs x split-K instead)
   if (a.act == 2) return a.img_rows % 128 == 0 ? 1 : 6;            // softmax epilogue: 128-wide tiles (t128x128s3 / t64x128s4)
@@ -1256,6 +1419,8 @@ static int pick_cfg(const GemmArgs& a) {
   if (a.N % 128 != 0 && a.N % 64 == 0 && a.N < 512) return 4;      // t128x64s4
   return 1;                                                        // t128x128s3
 }
+
+int sdmi_gemm_pick_cfg(const GemmArgs& a) { return pick_cfg(a); }
 
 size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int /*cfg*/, int ksplit) {
   return ksplit > 1 ? (size_t)ksplit * a.M * a.N * sizeof(float) : 0;
@@ -1299,6 +1464,10 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   }
   const int nkt = a.K / 64;
   GemmArgs p = a;
+  gnrec_magic(p.gacc);
+  if (p.gacc.rec && p.ksplit <= 1)
+    SDMI_REQUIRE(sdmi_gemm_gacc_ok(a, cfg) && a.gacc.parts == 2 && a.gacc.T == sdmi_gemm_gacc_T(a, cfg),
+                 "gemm: config %s cannot accumulate GroupNorm statistics for this shape (rows per image %d, T %d, parts %d)", c.name, a.gacc.rows_img, a.gacc.T, a.gacc.parts);
   if (p.lda0 <= 0) p.lda0 = p.C0;
   if (p.lda1 <= 0) p.lda1 = p.C1;
   if (p.ldw <= 0) p.ldw = p.K;
@@ -1354,18 +1523,53 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   }
   if (ksplit_out) *ksplit_out = p.ksplit;
   if (ksteps_per_out) *ksteps_per_out = p.ksteps_per;
-  if (p.ksplit > 1 && !p.no_finalize) {
-    const size_t total8 = (size_t)p.M * (p.N / 8);
-    int blocks = (int)((total8 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, st, p);
-    SDMI_CHECK_HIP(hipGetLastError());
-  }
+  if (p.ksplit > 1 && !p.no_finalize) return sdmi_launch_splitk_finalize(p, st);
   return SDMI_OK;
+}
+
+// rows per workgroup of the statistics-taking combine (0: this shape cannot take it): a multiple of the 8 rows per pass that
+// divides the rows of an image, few enough record rows, aiming at >= 256 workgroups
+static int finalize_gacc_rows(const GemmArgs& a) {
+  if (!a.gacc.rec || a.outT || a.N % kFinCols != 0 || !gacc_atom_ok(a.gacc.atom) || kFinCols % a.gacc.atom != 0 ||
+      a.gacc.natoms * a.gacc.atom != a.N || a.gacc.rows_img <= 0 || a.gacc.mod % a.gacc.rows_img != 0 || a.M % a.gacc.mod != 0)
+    return 0;
+  const int nsl = a.N / kFinCols, phases = a.M / a.gacc.mod;
+  int rows = 8;
+  if (a.gacc.rows_img % rows != 0) return 0;
+  auto recs = [&](int r) { return (long)phases * (a.gacc.rows_img / r) * a.gacc.natoms; };
+  while (recs(rows) > kGaccMaxRec) {
+    if (a.gacc.rows_img % (rows * 2) != 0) return 0;
+    rows *= 2;
+  }
+  while (rows < 64 && a.gacc.rows_img % (rows * 2) == 0 && (long)(a.M / (rows * 2)) * nsl >= 256) rows *= 2;
+  return rows <= 64 ? rows : 0;           // (8 items per thread at most: kernel instantiations below)
+}
+bool sdmi_finalize_gacc_ok(const GemmArgs& a, int* T_out) {
+  const int rows = finalize_gacc_rows(a);
+  if (rows > 0 && T_out) *T_out = (a.M / a.gacc.mod) * (a.gacc.rows_img / rows);
+  return rows > 0;
 }
 
 int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st) {
   SDMI_REQUIRE((size_t)a.M * (a.N / 8) < ((size_t)1 << 31), "splitk_finalize: M*N too large");
+  if (a.gacc.rec) {
+    GemmArgs ag = a;
+    gnrec_magic(ag.gacc);
+    const GemmArgs& a = ag;
+    const int rows = finalize_gacc_rows(a);
+    SDMI_REQUIRE(rows > 0, "splitk_finalize: GroupNorm statistics were asked of a shape the combine cannot take (N=%d)", a.N);
+    SDMI_REQUIRE(a.gacc.parts == 1 && a.gacc.T == (a.M / a.gacc.mod) * (a.gacc.rows_img / rows), "splitk_finalize: statistics record rows T=%d parts=%d do not match the launch", a.gacc.T, a.gacc.parts);
+    const int nsl = a.N / kFinCols;
+    const dim3 grid((a.M / rows) * nsl), block(kFinNT);
+    switch (rows / 8) {
+      case 1: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<1>, grid, block, 0, st, a, nsl); break;
+      case 2: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<2>, grid, block, 0, st, a, nsl); break;
+      case 4: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<4>, grid, block, 0, st, a, nsl); break;
+      default: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<8>, grid, block, 0, st, a, nsl); break;
+    }
+    SDMI_CHECK_HIP(hipGetLastError());
+    return SDMI_OK;
+  }
   const size_t total8 = (size_t)a.M * (a.N / 8);
   int blocks = (int)((total8 + 255) / 256);
   if (blocks > 2048) blocks = 2048;

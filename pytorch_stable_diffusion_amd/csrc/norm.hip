@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 4 per thread
   constexpr int IT = 4;
   float v[IT][8];
+  f32x4 ga_[IT], gb_[IT], ba_[IT], bb_[IT];
   int px_[IT], c_[IT];
   bool ok[IT];
   const int q_first = tid / C8, r_first = tid - q_first * C8;     // item = tid + 256 k -> (pixel, chunk) incrementally
@@ -108,8 +109,53 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     const int cs = second ? p.C1 : p.C0;
     const int cc = second ? c_[k] - p.C0 : c_[k];
     if (ok[k]) load8(base, p.in_f32, ((size_t)n * p.P + px_[k]) * cs + cc, v[k]);
+    // the layer's gamma / beta come from HBM (every weight is read once per step): requested here, with the activations,
+    // instead of behind the statistics (one more exposed memory latency per launch)
+    ga_[k] = *(const f32x4*)(p.gamma + c_[k]); gb_[k] = *(const f32x4*)(p.gamma + c_[k] + 4);
+    ba_[k] = *(const f32x4*)(p.beta + c_[k]); bb_[k] = *(const f32x4*)(p.beta + c_[k] + 4);
   }
-  {
+  if (p.acc0 != nullptr) {
+    // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 8)
+    // adds up its share of the group's records -- apg atoms x T record rows (x parts), per concat source -- all loads in flight
+    // at once, then the shares meet in LDS exactly as the chunk partials below do.  One pass, no statistics launch.
+    const int g = tid & 31, sl = tid >> 5;
+    const int apg = cpg / p.atom, na0 = p.C0 / p.atom;
+    const int Tmax = max(p.accT0, p.accT1);
+    const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 8, ...
+    constexpr int MAXR = 16;
+    f32x4 rv[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int f = sl + 8 * k;
+      rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f < npair) {
+        const int t = f / apg, a = g * apg + (f - t * apg);             // atom index in concat channel space
+        const bool second = a >= na0;
+        const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
+        if (t < T) {
+          const float* r = (second ? p.acc1 : p.acc0) + ((size_t)(n * T + t) * (second ? p.C1 / p.atom : na0) + (second ? a - na0 : a)) * parts * 2;
+          if (parts == 2) rv[k] = *(const f32x4*)r;
+          else { const f32x2 u = *(const f32x2*)r; rv[k][0] = u[0]; rv[k][1] = u[1]; }
+        }
+      }
+    }
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) { s += (double)rv[k][0] + (double)rv[k][2]; q += (double)rv[k][1] + (double)rv[k][3]; }
+    for (int f = sl + 8 * MAXR; f < npair; f += 8) {      // (more records than the producers' bound allows: still correct)
+      const int t = f / apg, a = g * apg + (f - t * apg);
+      const bool second = a >= na0;
+      const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
+      if (t < T) {
+        const float* r = (second ? p.acc1 : p.acc0) + ((size_t)(n * T + t) * (second ? p.C1 / p.atom : na0) + (second ? a - na0 : a)) * parts * 2;
+        s += (double)r[0]; q += (double)r[1];
+        if (parts == 2) { s += (double)r[2]; q += (double)r[3]; }
+      }
+    }
+    s_red[sl][g][0] = s;
+    s_red[sl][g][1] = q;
+  } else {
+    // (statistics: the chunk partials of gn_stats_kernel)
     const int g = tid & 31, sl = tid >> 5;
     double s = 0.0, q = 0.0;
     // nchunk <= 128 -> at most 16 chunks per slice: all loads issued at once (one latency round)
@@ -144,8 +190,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   for (int k = 0; k < IT; ++k) {               // phase B: normalise (+SiLU), convert, store
     if (!ok[k]) continue;
     const int c = c_[k];
-    const f32x4 ga = *(const f32x4*)(p.gamma + c), gb = *(const f32x4*)(p.gamma + c + 4);
-    const f32x4 ba = *(const f32x4*)(p.beta + c), bb = *(const f32x4*)(p.beta + c + 4);
+    const f32x4 ga = ga_[k], gb = gb_[k], ba = ba_[k], bb = bb_[k];
     f16x8 o;
     const int g0 = c / cpg;                      // one division per item; cpg >= 4, so c+e is at most 2 groups further
     const int r0 = c - g0 * cpg;
@@ -379,6 +424,7 @@ int sdmi_gn_nchunk(int P) {
 
 // 1 when the single-launch kernel takes this shape (slab of one group fits the block's registers), else 2
 int sdmi_gn_launches(const GnArgs& a) {
+  if (a.acc0) return 1;
   static const int max_px = getenv("SDMI_GN_FUSED_MAXPX") ? atoi(getenv("SDMI_GN_FUSED_MAXPX")) : 1024;   // up to 32x32 the one launch is as fast as stats + apply (same-box 4.277 vs 4.281 ms/step, 11 launches fewer); beyond, 64 blocks cannot pull the map fast enough
   const int C = a.C0 + a.C1, cpg = C / 32;
   const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
@@ -392,6 +438,18 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   SDMI_REQUIRE(a.nchunk == sdmi_gn_nchunk(a.P), "groupnorm: nchunk mismatch");
   SDMI_REQUIRE(!a.slab || (a.C1 == 0 && a.ksplit >= 1 && sdmi_gn_launches(a) == 1),
                "groupnorm: the split-K slab input needs one source and a map the single-launch kernel takes");
+  if (a.acc0) {
+    const int cpg = C / 32;
+    SDMI_REQUIRE(!a.slab && a.atom >= 4 && cpg % a.atom == 0 && a.C0 % a.atom == 0 && (a.C1 == 0 || a.acc1) && cpg / a.atom <= 8 && C % 32 == 0 &&
+                     a.accT0 > 0 && (a.accP0 == 1 || a.accP0 == 2) && (a.C1 == 0 || (a.accT1 > 0 && (a.accP1 == 1 || a.accP1 == 2))),
+                 "groupnorm: producer statistics need atoms that tile every group and both concat sources, T > 0 and parts 1 or 2");
+    const int C8a = C / 8;
+    int ppb = (256 * 4) / C8a;
+    if (ppb < 1) ppb = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(256), 0, st, a, ppb);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return SDMI_OK;
+  }
   if (sdmi_gn_launches(a) == 1) {
     {
       const long quads = ((long)a.P * (C / 128) + GNF_NT - 1) / GNF_NT;

@@ -224,6 +224,7 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   u->slab_bytes = (size_t)96 << 20;
   if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
   if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
+  u->gacc_enabled = true;                   // GroupNorm statistics from the producers' epilogues (engine.h attach_gacc)
   u->arena.cap = u->partial ? ((size_t)1 << 30) : ((size_t)6 << 30);
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) { sdmi_set_error("weight packing failed: %s", hipGetErrorString(hipGetLastError())); return fail(SDMI_EHIP); }
@@ -266,6 +267,7 @@ int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out) {
   u->slab_bytes = src->slab_bytes;
   if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
   if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
+  u->gacc_enabled = src->gacc_enabled;
   u->arena.cap = src->arena.cap;
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) return fail(SDMI_EHIP);
@@ -494,6 +496,26 @@ static int ensure_globals(size_t slab_need) {
   return SDMI_OK;
 }
 
+// statistics records of an op-level GEMM: fills a.gacc from the descriptor; T / parts as the launch will write them
+static int gacc_layout(const sdmi_gemm_desc* d, GemmArgs& a, int* T, int* parts) {
+  *T = 0; *parts = 0;
+  if (!d->gacc) return SDMI_OK;
+  SDMI_REQUIRE(d->gacc_atom >= 4 && d->N % d->gacc_atom == 0 && d->gacc_rows_img > 0, "op_gemm: bad statistics arguments");
+  a.gacc.rec = d->gacc; a.gacc.atom = d->gacc_atom; a.gacc.natoms = d->N / d->gacc_atom; a.gacc.rows_img = d->gacc_rows_img;
+  a.gacc.mod = d->phase2 ? d->M / 4 : d->M;
+  if (a.ksplit > 1) {
+    a.gacc.parts = 1;
+    SDMI_REQUIRE(sdmi_finalize_gacc_ok(a, &a.gacc.T), "op_gemm: the split-K combine cannot take GroupNorm statistics for this shape");
+  } else {
+    const int cfg = d->cfg < 0 ? sdmi_gemm_pick_cfg(a) : d->cfg;
+    a.gacc.parts = 2;
+    SDMI_REQUIRE(sdmi_gemm_gacc_ok(a, cfg), "op_gemm: config %s cannot accumulate GroupNorm statistics for this shape", sdmi_gemm_cfg_name(cfg));
+    a.gacc.T = sdmi_gemm_gacc_T(a, cfg);
+  }
+  *T = a.gacc.T; *parts = a.gacc.parts;
+  return SDMI_OK;
+}
+
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   if (!d) { sdmi_set_error("op_gemm: null desc"); return SDMI_EINVAL; }
   GemmArgs a;
@@ -512,7 +534,18 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
-  return sdmi_launch_gemm(a, d->cfg, (hipStream_t)stream);
+  int T = 0, parts = 0;
+  TRY(gacc_layout(d, a, &T, &parts));
+  return sdmi_launch_gemm(a, d->cfg < 0 ? sdmi_gemm_pick_cfg(a) : d->cfg, (hipStream_t)stream);
+}
+int sdmi_op_gemm_stat_layout(const sdmi_gemm_desc* d, int* T, int* parts) {
+  if (!d || !T || !parts) { sdmi_set_error("op_gemm_stat_layout: null argument"); return SDMI_EINVAL; }
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = d->M; a.N = d->N; a.K = d->K; a.ks = d->ks; a.phase2 = d->phase2; a.img_rows = d->img_rows; a.act = d->act;
+  a.outT = (f16*)d->out_t; a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+  SDMI_REQUIRE(d->gacc != nullptr, "op_gemm_stat_layout: the descriptor asks for no statistics");
+  return gacc_layout(d, a, T, parts);
 }
 // Micro-benchmark: `iters` back-to-back launches bracketed by two HIP events on `stream`; iters < 0: -iters launches timed one
 // by one, each behind a 64 MiB fill that evicts the eight L2s (the state a GEMM finds inside the denoising step: csrc/engine.h
@@ -566,6 +599,11 @@ int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* str
   a.npass2 = d->npass2 > 0 ? d->npass2 : 1; a.ldo = d->ldo > 0 ? d->ldo : 320; a.vt = (f16*)d->vt; a.S = d->S; a.ldt = d->ldt;
   a.gx = d->gx; a.gx_f32 = d->gx_f32; a.gn_partial = d->gn_partial; a.gn_nchunk = d->gn_nchunk; a.gn_gamma = d->gn_gamma;
   a.gn_beta = d->gn_beta; a.gn_eps = d->gn_eps;
+  if (d->gacc) {
+    SDMI_REQUIRE(d->gacc_atom >= 4 && 320 % d->gacc_atom == 0 && d->gacc_rows_img > 0, "op_b2b: bad statistics arguments");
+    a.gacc.rec = d->gacc; a.gacc.atom = d->gacc_atom; a.gacc.natoms = 320 / d->gacc_atom; a.gacc.rows_img = d->gacc_rows_img; a.gacc.mod = d->M;
+    a.gacc.T = d->gacc_rows_img / 32; a.gacc.parts = 1;          // one record row per 32-row tile
+  }
   hipStream_t st = (hipStream_t)stream;
   if (!us_per_iter) {
     for (int i = 0; i < iters; ++i) TRY(sdmi_launch_b2b(a, st, d->bm));
@@ -622,6 +660,20 @@ int sdmi_op_groupnorm(const void* x0, const void* x1, int in_f32, int c0, int c1
   memset(&g, 0, sizeof(g));
   g.x0 = x0; g.x1 = x1; g.in_f32 = in_f32; g.C0 = c0; g.C1 = c1; g.B = B; g.P = P; g.gamma = gamma; g.beta = beta;
   g.eps = eps; g.silu = silu; g.y = (f16*)y_f16; g.partial = partial; g.nchunk = sdmi_gn_nchunk(P);
+  return sdmi_launch_groupnorm(g, (hipStream_t)stream);
+}
+
+int sdmi_op_groupnorm_acc(const void* x0, const void* x1, int in_f32, int c0, int c1, int B, int P, const float* rec0, int T0,
+                          int parts0, const float* rec1, int T1, int parts1, int atom, const float* gamma, const float* beta,
+                          float eps, int silu, void* y_f16, void* stream) {
+  static float* partial = nullptr;
+  if (!partial) SDMI_CHECK_HIP(hipMalloc((void**)&partial, 256));
+  SDMI_REQUIRE(rec0 && atom >= 4, "op_groupnorm_acc: bad arguments");
+  GnArgs g;
+  memset(&g, 0, sizeof(g));
+  g.x0 = x0; g.x1 = x1; g.in_f32 = in_f32; g.C0 = c0; g.C1 = c1; g.B = B; g.P = P; g.gamma = gamma; g.beta = beta;
+  g.eps = eps; g.silu = silu; g.y = (f16*)y_f16; g.partial = partial; g.nchunk = sdmi_gn_nchunk(P);
+  g.acc0 = rec0; g.accT0 = T0; g.accP0 = parts0; g.acc1 = rec1; g.accT1 = T1; g.accP1 = parts1; g.atom = atom;
   return sdmi_launch_groupnorm(g, (hipStream_t)stream);
 }
 

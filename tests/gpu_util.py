@@ -48,8 +48,11 @@ def pack_ups_phase(w: torch.Tensor) -> torch.Tensor:
 def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bias=None, res=None,
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
-          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None):
-    """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given)."""
+          w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None, gstat_rows_img=0, gstat_atom=10):
+    """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given).
+    gstat_rows_img > 0: the launch also leaves the GroupNorm statistics of its output (sdmi_gemm_desc::gacc); they are returned
+    in LAST_STAT = (records [images][T][atoms][parts][2] fp32, T, parts).  ValueError if the config cannot take them."""
+    global LAST_STAT
     lib = N.load()
     d = N.GemmDesc()
     c0 = a0.shape[-1]
@@ -84,6 +87,14 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     if ln_stat is not None:
         d.ln_stat, d.ln_ntn, d.ln_g, d.ln_c, d.ln_eps = ln_stat.data_ptr(), ln_stat.shape[1], ln_g.data_ptr(), ln_c, ln_eps
     d.act, d.sm_valid, d.img_rows, d.w_img_stride, d.vec_img_stride, d.ldw = act, sm_valid, img_rows, w_img_stride, vec_img_stride, ldw
+    if gstat_rows_img:
+        d.gacc, d.gacc_atom, d.gacc_rows_img = 16, gstat_atom, gstat_rows_img          # (any non-null pointer for the layout query)
+        T, parts = C.c_int(0), C.c_int(0)
+        N.check(lib.sdmi_op_gemm_stat_layout(C.byref(d), C.byref(T), C.byref(parts)), "stat_layout")
+        imgs = (M // (4 if phase2 else 1)) // gstat_rows_img
+        rec = torch.full((imgs, T.value, Nn // gstat_atom, parts.value, 2), float("nan"), dtype=torch.float32, device=a0.device)
+        d.gacc = rec.data_ptr()
+        LAST_STAT = (rec, T.value, parts.value)
     N.check(lib.sdmi_op_gemm(C.byref(d), N.cur_stream()), "sdmi_op_gemm")
     torch.cuda.synchronize()
     return (out, out16) if want16 else out
@@ -131,6 +142,28 @@ def groupnorm(x0, x1, gamma, beta, eps, silu):
     y = torch.empty((B, H, W, c0 + c1), dtype=torch.float16, device=x0.device)
     N.check(lib.sdmi_op_groupnorm(N.ptr(x0), N.ptr(x1), int(x0.dtype == torch.float32), c0, c1, B, H * W,
                                   N.ptr(gamma), N.ptr(beta), eps, int(silu), N.ptr(y), N.cur_stream()), "gn")
+    torch.cuda.synchronize()
+    return y
+
+
+LAST_STAT = None
+
+
+def stat_moments(rec):
+    """records [images][T][atoms][parts][2] -> (sum, sumsq) per (image, atom) as float64"""
+    r = rec.cpu().double().sum(dim=(1, 3))
+    return r[..., 0], r[..., 1]
+
+
+def groupnorm_acc(x0, x1, st0, st1, gamma, beta, eps, silu, atom=10):
+    """st0 / st1: (records, T, parts) as igemm's LAST_STAT"""
+    lib = N.load()
+    B, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    y = torch.empty((B, H, W, c0 + c1), dtype=torch.float16, device=x0.device)
+    r1, T1, p1 = st1 if st1 is not None else (None, 0, 0)
+    N.check(lib.sdmi_op_groupnorm_acc(N.ptr(x0), N.ptr(x1), int(x0.dtype == torch.float32), c0, c1, B, H * W, N.ptr(st0[0]), st0[1], st0[2],
+                                      N.ptr(r1), T1, p1, atom, N.ptr(gamma), N.ptr(beta), eps, int(silu), N.ptr(y), N.cur_stream()), "gn_acc")
     torch.cuda.synchronize()
     return y
 

@@ -693,3 +693,132 @@ def test_partial_layernorm_fold_with_split_k(M, Cc, Nn):
     assert len(splits) >= 2
     for k in splits[1:]:
         assert (outs[k] - outs[1]).abs().max().item() < 2e-3, k
+
+
+def _atom_moments(x, B, atom=10):
+    """x [B*P][C] float64 -> (sum, sumsq) per (image, atom): what a producer's epilogue leaves behind"""
+    P, Cc = x.shape[0] // B, x.shape[1]
+    xa = x.view(B, P, Cc // atom, atom)
+    return xa.sum(dim=(1, 3)), (xa * xa).sum(dim=(1, 3))
+
+
+@pytest.mark.parametrize("B,P,Nn,K,ksplit,out_f32", [(2, 256, 320, 320, 1, True), (2, 1024, 640, 640, 1, False), (2, 256, 1280, 2560, 4, True),
+                                                     (1, 512, 640, 1280, 2, False), (2, 4096, 320, 320, 1, True)])
+def test_gemm_epilogue_groupnorm_statistics(B, P, Nn, K, ksplit, out_f32):
+    """GroupNorm statistics from the producer (include/sdmi.h sdmi_gemm_desc::gacc; sd/diffusion.py:173,199,294): every tile config that
+    can take them (one-pass epilogue) and the split-K combine leave, per image, row block and 10-channel atom, the moments of
+    exactly the values they store; every record slot is written (none stays NaN), and two launches give the same bits."""
+    from pytorch_stable_diffusion_amd import _native as N
+    lib = N.load()
+    M = B * P
+    g = torch.Generator().manual_seed(P + Nn + K)
+    a = torch.randn((M, K), generator=g).half()
+    w = (torch.randn((Nn, K), generator=g) / math.sqrt(K)).half()
+    bias = torch.randn((Nn,), generator=g) * 3          # atoms with a large mean
+    res = torch.randn((M, Nn), generator=g)
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    tried = 0
+    for cfg in _plain_cfgs():
+        bm, bn = G.gemm_tile(cfg)
+        if P % bm != 0 or bn % 64 != 0:
+            continue
+        kw = dict(B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=bias.to(DEV), res=res.to(DEV), out_f32=out_f32, cfg=cfg, ksplit=ksplit, gstat_rows_img=P)
+        try:
+            out = G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), **kw)
+        except ValueError as e:                            # SDMI_EINVAL: this tile cannot keep a thread's columns fixed
+            assert "cannot" in str(e) and "statistics" in str(e), e
+            continue
+        tried += 1
+        rec, T, parts = G.LAST_STAT
+        assert not torch.isnan(rec).any(), f"cfg {names[cfg]}: {int(torch.isnan(rec).sum())} record slots were never written"
+        assert parts == (1 if ksplit > 1 else 2) and rec.shape[0] == B
+        s1, s2 = G.stat_moments(rec)
+        r1, r2 = _atom_moments(out.cpu().double(), B)
+        e1 = ((s1 - r1).abs() / (r1.abs() + P * 1.0)).max().item()
+        e2 = ((s2 - r2).abs() / r2).max().item()
+        assert e1 < 2e-6 and e2 < 2e-6, f"cfg {names[cfg]} split {ksplit}: sum err {e1}, sumsq err {e2}"
+        G.igemm(a.to(DEV).view(1, M, 1, K), w.to(DEV), **kw)
+        assert torch.equal(rec, G.LAST_STAT[0]), f"cfg {names[cfg]}: records differ between two launches"
+        if ksplit > 1 and tried >= 3:
+            break
+    assert tried >= (1 if ksplit > 1 else 8), tried
+
+
+@pytest.mark.parametrize("C0,C1,P,in_f32,silu,offset", [(320, 0, 4096, True, True, 0.0), (640, 320, 1024, True, True, 0.0),
+                                                        (1280, 640, 256, False, False, 0.0), (320, 320, 4096, True, True, 30.0),
+                                                        (1280, 1280, 256, True, True, -30.0), (320, 0, 4096, True, True, 100.0)])
+def test_groupnorm_from_producer_statistics(C0, C1, P, in_f32, silu, offset):
+    """One normalising pass over statistics the producers left behind (sdmi_op_groupnorm_acc): each concat source has its own
+    records, groups of (C0 + C1) / 32 = 10 .. 80 channels are sums of 10-channel atoms.  The sources are written here by plain
+    GEMMs with K = 64 (their epilogues take the statistics), the second one with another tile config (other T) than the first."""
+    B = 2
+    Hh = int(math.isqrt(P))
+    g = torch.Generator().manual_seed(C0 + C1 + P)
+    gamma = 1 + 0.1 * torch.randn((C0 + C1,), generator=g)
+    beta = 0.1 * torch.randn((C0 + C1,), generator=g)
+    xs, sts = [], []
+    for Cs, cfg in ((C0, -1), (C1, 9)):
+        if Cs == 0:
+            xs.append(None); sts.append(None)
+            continue
+        a = torch.randn((B * P, 64), generator=g).half()
+        w = (torch.randn((Cs, 64), generator=g) / 8).half()
+        bias = torch.randn((Cs,), generator=g) * 0.5 + offset
+        out = G.igemm(a.to(DEV).view(1, B * P, 1, 64), w.to(DEV), B=1, Hs=B * P, Ws=1, Ho=B * P, Wo=1, bias=bias.to(DEV),
+                      out_f32=in_f32, cfg=cfg, gstat_rows_img=P)
+        xs.append(out.view(B, Hh, Hh, Cs))
+        sts.append(G.LAST_STAT)
+    x = torch.cat([t.cpu().double() for t in xs if t is not None], dim=-1)
+    ref = F.group_norm(x.permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
+    y = G.groupnorm_acc(xs[0], xs[1], sts[0], sts[1], gamma.to(DEV), beta.to(DEV), 1e-5, silu)
+    err = (y.cpu().double() - ref).abs().max().item()
+    y2 = G.groupnorm(xs[0], xs[1], gamma.to(DEV), beta.to(DEV), 1e-5, silu)          # the library's own statistics
+    d2 = (y.float() - y2.float()).abs().max().item()
+    G.log_metric(test="groupnorm_acc", C0=C0, C1=C1, P=P, offset=offset, max_abs_err=err, vs_own_stats=d2)
+    assert err < (4e-3 if abs(offset) <= 30 else 8e-3), f"max abs err {err}"
+    assert d2 < 4e-3, f"differs from the statistics-launch path by {d2}"
+
+
+def test_back_to_back_gemm_groupnorm_statistics():
+    """the feed-forward form of csrc/b2b.hip (the attention block's output at 64x64) leaves the statistics of its output"""
+    import ctypes as C
+    Cc, B, P = 320, 2, 128
+    M = B * P
+    g = torch.Generator().manual_seed(5)
+    a1 = torch.randn((M, Cc), generator=g).half()
+    w1 = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    b1 = torch.randn((Cc,), generator=g)
+    r1 = torch.randn((M, Cc), generator=g)
+    r2 = torch.randn((M, Cc), generator=g) + 2.0
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    w2 = torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)
+    b2 = torch.randn((Cc,), generator=g)
+    wp = (torch.randn((Cc, Cc), generator=g) / math.sqrt(Cc)).half()
+    wf, _, hf = G.ln_fold_prep(w2.to(DEV), gamma.to(DEV), beta.to(DEV), b2.to(DEV))
+    wf = torch.cat([wf, wp.to(DEV)], dim=1).contiguous()
+    a1d, w1d, b1d, r1d, r2d = a1.to(DEV), w1.to(DEV), b1.to(DEV), r1.to(DEV), r2.to(DEV)
+    outs = []
+    for with_acc in (False, True):
+        out = torch.full((M, Cc), float("nan"), device=DEV)
+        out16 = torch.full((M, Cc), float("nan"), dtype=torch.float16, device=DEV)
+        rec = torch.full((B, P // 32, Cc // 10, 1, 2), float("nan"), device=DEV)
+        d = N_.B2bDesc()
+        d.a1, d.lda1, d.w1, d.b1 = a1d.data_ptr(), Cc, w1d.data_ptr(), b1d.data_ptr()
+        d.r1, d.r1_f32 = r1d.data_ptr(), 1
+        d.w2, d.K2, d.h2, d.partial, d.cscale = wf.data_ptr(), 640, hf.data_ptr(), 1, 0.0
+        d.r2, d.r2_f32 = r2d.data_ptr(), 1
+        d.out, d.out_f32, d.out16 = out.data_ptr(), 1, out16.data_ptr()
+        d.M, d.eps, d.bm = M, 1e-5, 32
+        if with_acc:
+            d.gacc, d.gacc_atom, d.gacc_rows_img = rec.data_ptr(), 10, P
+        N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b")
+        torch.cuda.synchronize()
+        outs.append((out.clone(), out16.clone(), rec))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # the statistics form stores the same bits
+    assert not torch.isnan(outs[1][2]).any()
+    s1, s2 = G.stat_moments(outs[1][2])
+    r1m, r2m = _atom_moments(outs[1][1].float().cpu().double(), B)                          # moments of the fp16 values (b2b.hip)
+    assert ((s1 - r1m).abs() / (r1m.abs() + P)).max().item() < 2e-6
+    assert ((s2 - r2m).abs() / r2m).max().item() < 2e-6

@@ -18,6 +18,7 @@ import sys
 
 KIND_PAT = {"igemm": "igemm_kernel", "halo": "conv3_halo_kernel", "finalize": "splitk_finalize", "attn": "attn_kernel",
             "gn_fused": "gn_fused_kernel", "gn_fused_slab": "gn_fused_kernel", "gn_stats": "gn_stats_kernel", "gn_apply": "gn_apply_kernel",
+            "gn_apply_acc": "gn_apply_kernel",
             "layernorm": "layernorm_kernel", "stem": "stem_conv", "final_conv": "final_conv", "xattn": "xattn", "b2b": "b2b_kernel"}
 
 
