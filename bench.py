@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--chains", type=int, default=1,
                     help="throughput mode, reported beside the single-chain headline: this many independent denoising loops "
                          "(lanes over ONE copy of the packed weights) run concurrently on the GPU, one HIP stream each")
+    ap.add_argument("--batch-prompts", type=int, default=0,
+                    help="throughput mode, reported beside the single-chain headline: this many independent prompts through ONE "
+                         "chain of launches (UNet batch 2P, per-prompt latents / noise / context; sdmi_unet_denoise_step_batch)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also time BASELINE configs[0] end to end on the host CPU (oracle CLIP x2 + 20 CFG steps + VAE "
@@ -326,6 +329,46 @@ def main():
         model.set_context(ctx)
         model.set_schedule(temb)
 
+    # ---- throughput mode (--batch-prompts P): P prompts through ONE chain, UNet batch 2P.  Reported beside the headline, never
+    # as `value`: every weight is streamed once per step for the P prompts, the launch-bound 16x16 / 8x8 levels do P times the work
+    # per launch.  Aggregate steps/s = P x steps / time (one "step" stays one prompt's CFG step).
+    batched = None
+    if rank == 0 and world == 1 and args.batch_prompts > 1:
+        P = args.batch_prompts
+        ctx_p = torch.cat([torch.randn((P, 77, 768), generator=torch.Generator().manual_seed(11)),
+                           torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(12)).repeat(P, 1, 1)]).to(dev)
+        latp0 = torch.randn((P, 4, hw, hw), generator=torch.Generator().manual_seed(13)).to(dev)
+        noise_p = torch.randn((50, P, 4, hw, hw), generator=torch.Generator().manual_seed(14)).to(dev)
+        model.set_context(ctx_p)
+        model.set_schedule(temb)
+        latp = latp0.clone()
+
+        def run_p(n_steps):
+            for i in range(n_steps):
+                j = i % 50
+                if j == 0:
+                    latp.copy_(latp0)
+                h.denoise_step(latp, j, True, 7.5, noise_p[j] if ts[j] > 0 else None, coefs[j])
+
+        tb0 = time.time()
+        run_p(1)                           # shapes of this batch missing from the plan tables are tuned here
+        torch.cuda.synchronize()
+        t_first_p = time.time() - tb0
+        run_p(args.warmup)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        run_p(args.steps)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb0
+        batched = {"prompts": P, "unet_batch": 2 * P, "steps_per_s_aggregate": round(P * args.steps / dtb, 3),
+                   "ms_per_batched_step": round(dtb / args.steps * 1e3, 3), "launches_per_batched_step": h.last_launch_count + 1,
+                   "first_step_s": round(t_first_p, 2), "gemm_shapes_tuned_in_process": h.tuned_shapes - tuned_shapes,
+                   "note": "P independent prompts (own latents, noise stream, contexts) through one chain of launches at UNet batch "
+                           "2P (pipeline.generate_batch / replicas.run_prompts(batch_per_gpu=P) are the generate()-level forms); "
+                           "unmeasured on 8 GPUs"}
+        model.set_context(ctx)
+        model.set_schedule(temb)
+
     # ---- 50-step image latency: the drop-in generate() end to end (CLIP x2 + 50 fused steps + VAE decode)
     image_latency = None
     if rank == 0 and world == 1 and not args.no_image_latency and hw == 64:
@@ -428,6 +471,8 @@ def main():
         }
         if chains is not None:
             out["throughput_mode"] = chains
+        if batched is not None:
+            out["batched_prompts"] = batched
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

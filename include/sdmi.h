@@ -67,8 +67,8 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
 int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, void* stream);
 
 /* Replaces Diffusion.forward (sd/diffusion.py:797-837) on NCHW fp32 I/O like the reference.
- * latents_dev: (latent_batch, 4, h, w) fp32; latent_batch == 1 with batch == 2 implements the CFG
- * `repeat(2,1,1,1)` (sd/pipeline.py:221) without a copy.  Time input: temb_dev != NULL -> (1,320)
+ * latents_dev: (latent_batch, 4, h, w) fp32, latent_batch divides batch: image b reads latent b mod latent_batch, i.e. the CFG
+ * `repeat(2,1,1,1)` (sd/pipeline.py:221) without a copy (latent_batch == 1 with batch == 2 in generate()).  Time input: temb_dev != NULL -> (1,320)
  * fp32 embedding used directly; else row step_idx of the schedule.  eps_out_dev: (batch,4,h,w) fp32. */
 int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev,
                       int step_idx, float* eps_out_dev, int batch, int h, int w, void* stream);
@@ -85,6 +85,12 @@ int sdmi_cfg_ddpm_step(const float* eps_dev, int do_cfg, float cfg_scale, float*
  * eps buffer (the loop body of sd/pipeline.py:208-237). */
 int sdmi_unet_denoise_step(sdmi_unet* u, float* latents_dev, int step_idx, int do_cfg, float cfg_scale,
                            const float* noise_dev, const float* coef, int h, int w, void* stream);
+/* The same for n_prompts independent prompts through ONE chain (throughput mode; sd/pipeline.py:146: generate() itself is
+ * batch 1 per call): latents_dev / noise_dev are (n_prompts,4,h,w), the UNet runs batch 2*n_prompts (n_prompts without
+ * guidance) in the order cat([cond_0..cond_P-1, uncond_0..uncond_P-1]) -- the context given to sdmi_unet_set_context must
+ * have that batch and order -- and every prompt is at step step_idx of the one schedule (coef as above).  2*n_prompts <= 16. */
+int sdmi_unet_denoise_step_batch(sdmi_unet* u, float* latents_dev, int n_prompts, int step_idx, int do_cfg, float cfg_scale,
+                                 const float* noise_dev, const float* coef, int h, int w, void* stream);
 
 /* Block-level entry points (parity tests): run ONE reference sub-module on NHWC fp32 device tensors.
  * kind: 0 = UNET_ResidualBlock (sd/diffusion.py:145-209; time_dev = (1,1280) TimeEmbedding output),

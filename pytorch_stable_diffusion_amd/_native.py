@@ -68,6 +68,8 @@ _SIGNATURES = {
                                      C.c_int64, C.c_void_p, C.c_void_p]),
     "sdmi_unet_denoise_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                          C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_unet_denoise_step_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                               C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "sdmi_unet_run_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdmi_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -395,12 +397,15 @@ class UNetHandle(_DeviceBound):
 
     def denoise_step(self, latents: torch.Tensor, step_idx: int, do_cfg: bool, cfg_scale: float,
                      noise: Optional[torch.Tensor], coef):
+        """latents (P,4,h,w), updated in place; P > 1: P prompts through one chain (the context set before has batch 2P -- P without
+        guidance -- in the order cat([cond_0..cond_P-1, uncond_0..uncond_P-1]); noise (P,4,h,w) or None)."""
         self._on_dev(latents, noise)
-        _, _, h, w = latents.shape
+        n_prompts, _, h, w = latents.shape
+        assert latents.is_contiguous() and (noise is None or (noise.is_contiguous() and noise.shape == latents.shape))
         c = (C.c_float * 5)(*[float(x) for x in coef])
         with self._guard():
-            check(self._lib.sdmi_unet_denoise_step(self._h, ptr(latents), step_idx, int(do_cfg), float(cfg_scale),
-                                                   ptr(noise), c, h, w, self._stream()), "sdmi_unet_denoise_step")
+            check(self._lib.sdmi_unet_denoise_step_batch(self._h, ptr(latents), n_prompts, step_idx, int(do_cfg), float(cfg_scale),
+                                                         ptr(noise), c, h, w, self._stream()), "sdmi_unet_denoise_step_batch")
 
     def run_block(self, prefix: str, kind: int, x0: torch.Tensor, x1: Optional[torch.Tensor] = None,
                   time: Optional[torch.Tensor] = None, arg: int = 1, out_shape=None) -> torch.Tensor:

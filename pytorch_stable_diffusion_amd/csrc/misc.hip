@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int la
     const int ow = (int)(pix - prow * W);
     const int b = (int)(prow / (unsigned)H);
     const int oh = (int)(prow - (unsigned)b * H);
-    const int lb = lat_batch == 1 ? 0 : b;
+    const int lb = b % lat_batch;                 // latents.repeat(batch / lat_batch, 1, 1, 1): image b reads latent b mod lat_batch
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = bias[c8 * 8 + e];

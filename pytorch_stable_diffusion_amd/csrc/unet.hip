@@ -351,7 +351,7 @@ int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, voi
 int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev, int step_idx,
                       float* eps_out_dev, int batch, int h, int w, void* stream) {
   if (!u || !latents_dev || !eps_out_dev) { sdmi_set_error("forward: null argument"); return SDMI_EINVAL; }
-  SDMI_REQUIRE(latent_batch == batch || latent_batch == 1, "forward: latent_batch=%d vs batch=%d", latent_batch, batch);
+  SDMI_REQUIRE(latent_batch >= 1 && batch % latent_batch == 0, "forward: latent_batch=%d must divide batch=%d", latent_batch, batch);
   SDMI_REQUIRE(h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "forward: latent size %dx%d must be multiples of 8", h, w);
   SDMI_REQUIRE(u->has_stem && u->has_final && u->has_time, "forward: incomplete weights (handle created with SDMI_FLAG_PARTIAL?)");
   TRY(u->enter(stream));
@@ -402,16 +402,27 @@ int sdmi_cfg_ddpm_step(const float* eps_dev, int do_cfg, float cfg_scale, float*
 
 int sdmi_unet_denoise_step(sdmi_unet* u, float* latents_dev, int step_idx, int do_cfg, float cfg_scale,
                            const float* noise_dev, const float* coef, int h, int w, void* stream) {
+  return sdmi_unet_denoise_step_batch(u, latents_dev, 1, step_idx, do_cfg, cfg_scale, noise_dev, coef, h, w, stream);
+}
+
+// P prompts through ONE chain (throughput mode): the UNet runs batch 2P (P with guidance off) -- the P conditional images first,
+// then the P unconditional ones, exactly latents.repeat(2, 1, 1, 1) / cat([cond, uncond]) of sd/pipeline.py:118-122,221 at
+// latent batch P -- so every weight is read once for P prompts and the launch-bound low-resolution levels do P times the work
+// per launch.  All prompts are at the same step of the same schedule (same coef); the context set by sdmi_unet_set_context
+// has batch 2P in that order.
+int sdmi_unet_denoise_step_batch(sdmi_unet* u, float* latents_dev, int n_prompts, int step_idx, int do_cfg, float cfg_scale,
+                                 const float* noise_dev, const float* coef, int h, int w, void* stream) {
   if (!u) { sdmi_set_error("denoise_step: null handle"); return SDMI_EINVAL; }
+  SDMI_REQUIRE(n_prompts >= 1 && n_prompts * (do_cfg ? 2 : 1) <= 16, "denoise_step: %d prompts (batch <= 16)", n_prompts);
   TRY(u->enter(stream));             // before any allocation: eps_buf must live on the handle's device
-  const int batch = do_cfg ? 2 : 1;
+  const int batch = (do_cfg ? 2 : 1) * n_prompts;
   const size_t need = (size_t)batch * 4 * h * w;
   if (u->eps_elems < need) {
     TRY(u->dmalloc(&u->eps_buf, need * 4));
     u->eps_elems = need;
   }
-  TRY(sdmi_unet_forward(u, latents_dev, 1, nullptr, step_idx, u->eps_buf, batch, h, w, stream));
-  TRY(sdmi_launch_cfg_ddpm(u->eps_buf, do_cfg, cfg_scale, latents_dev, noise_dev, coef, (size_t)4 * h * w, nullptr, (hipStream_t)stream));
+  TRY(sdmi_unet_forward(u, latents_dev, n_prompts, nullptr, step_idx, u->eps_buf, batch, h, w, stream));
+  TRY(sdmi_launch_cfg_ddpm(u->eps_buf, do_cfg, cfg_scale, latents_dev, noise_dev, coef, (size_t)n_prompts * 4 * h * w, nullptr, (hipStream_t)stream));
   u->launches += 1;
   return SDMI_OK;
 }

@@ -168,6 +168,26 @@ class Diffusion:
             self.step(lat, i, do_cfg, cfg_scale, noise, sampler.step_coefficients(t))
         return lat
 
+    @torch.no_grad()
+    def denoise_native_batch(self, latents: torch.Tensor, context: torch.Tensor, samplers, timesteps, do_cfg: bool,
+                             cfg_scale: float) -> torch.Tensor:
+        """P independent prompts through ONE chain of launches (throughput mode): latents (P,4,h,w); context (2P,77,768) =
+        cat([cond_0..cond_P-1, uncond_0..uncond_P-1]) ((P,77,768) without guidance); samplers: one DDPMSampler per prompt, each
+        with its own generator -- prompt i's noise stream is the one its own generate() call would draw -- all on the same
+        timesteps.  Every weight is read once per step for the P prompts."""
+        from .pipeline import get_time_embedding
+        lat = latents.to(self._device, torch.float32).contiguous().clone()
+        P = lat.shape[0]
+        if len(samplers) != P or context.shape[0] != (2 if do_cfg else 1) * P:
+            raise ValueError(f"denoise_native_batch: {P} latents, {len(samplers)} samplers, context batch {context.shape[0]}")
+        self.set_context(context)
+        self.set_schedule(torch.cat([get_time_embedding(t) for t in timesteps]))
+        one = (1,) + tuple(lat.shape[1:])
+        for i, t in enumerate(timesteps):
+            noise = torch.cat([s.draw_noise(one, self._device) for s in samplers]) if t > 0 else None
+            self.step(lat, i, do_cfg, cfg_scale, noise, samplers[0].step_coefficients(t))
+        return lat
+
     # ---- reference call convention -------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, latent: torch.Tensor, context: torch.Tensor, time: torch.Tensor) -> torch.Tensor:

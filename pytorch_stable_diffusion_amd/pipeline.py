@@ -124,3 +124,68 @@ def generate(prompt, uncond_prompt=None, input_image=None, strength=0.8, do_cfg=
         images = images.permute(0, 2, 3, 1)
         images = images.to("cpu", torch.uint8).numpy()      # truncating cast, as the reference
         return images[0]
+
+
+def generate_batch(prompts, uncond_prompt="", seeds=None, do_cfg=True, cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=50,
+                   models={}, device=None, idle_device=None, tokenizer=None, height=HEIGHT, width=WIDTH, rng_device="cpu"):
+    """``len(prompts)`` txt2img calls of ``generate()`` as ONE batched denoising loop (throughput mode: more prompts than GPUs).
+    Prompt i gets exactly what ``generate(prompt=prompts[i], seed=seeds[i], ...)`` would give it -- its own generator, the same
+    draw order (initial latents, then one draw per step with t > 0), its own CLIP contexts, its own VAE decode -- but the UNet
+    runs batch 2P through one chain of launches (``Diffusion.denoise_native_batch``), so the weights are streamed once per step
+    for all P prompts and the launch-bound low-resolution levels do P times the work per launch.  Same numerics up to the tile
+    plans of the larger GEMMs.  At most 8 prompts (UNet batch 16).  Returns a list of (H, W, 3) uint8 images."""
+    with torch.no_grad():
+        if height % 64 or width % 64:
+            raise ValueError(f"height/width must be multiples of 64, got {height}x{width}")
+        P = len(prompts)
+        if not 1 <= P <= (8 if do_cfg else 16):
+            raise ValueError(f"generate_batch: {P} prompts (1 .. {8 if do_cfg else 16})")
+        if seeds is None:
+            seeds = [None] * P
+        if len(seeds) != P:
+            raise ValueError("generate_batch: one seed per prompt")
+        if sampler_name != "ddpm":
+            raise ValueError(f"Sampler {sampler_name} not found")
+        to_idle = (lambda x: x.to(idle_device)) if idle_device else (lambda x: x)
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        device = torch.device(device)
+        gens = []
+        for sd_ in seeds:
+            g = torch.Generator(device=rng_device if rng_device is not None else device)
+            if sd_ is None:
+                g.seed()
+            else:
+                g.manual_seed(sd_)
+            gens.append(g)
+        clip = models["clip"]
+        clip.to(device)
+        cond = [_encode_prompt(tokenizer, clip, p, device) for p in prompts]
+        if do_cfg:
+            un = _encode_prompt(tokenizer, clip, uncond_prompt, device)
+            context = torch.cat(cond + [un] * P)                  # all conditional contexts first (sd/pipeline.py:122 at batch P)
+        else:
+            context = torch.cat(cond)
+        to_idle(clip)
+        samplers = []
+        for g in gens:
+            sm = DDPMSampler(g)
+            sm.set_inference_timesteps(n_inference_steps)
+            samplers.append(sm)
+        shape1 = (1, 4, height // 8, width // 8)
+        latents = torch.cat([torch.randn(shape1, generator=g, device=g.device).to(device) for g in gens])
+        diffusion = models["diffusion"]
+        diffusion.to(device)
+        if not hasattr(diffusion, "denoise_native_batch"):
+            raise TypeError("generate_batch needs this package's Diffusion (denoise_native_batch)")
+        latents = diffusion.denoise_native_batch(latents, context, samplers, samplers[0].timesteps.tolist(), do_cfg, cfg_scale)
+        to_idle(diffusion)
+        decoder = models["decoder"]
+        decoder.to(device)
+        out = []
+        for i in range(P):
+            images = decoder(latents[i:i + 1].clone())
+            images = rescale(images, (-1, 1), (0, 255), clamp=True)
+            out.append(images.permute(0, 2, 3, 1).to("cpu", torch.uint8).numpy()[0])
+        to_idle(decoder)
+        return out

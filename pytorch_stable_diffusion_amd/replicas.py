@@ -226,19 +226,30 @@ def lane_models(models: Dict[str, object], n_lanes: int, device=None) -> List[Di
 def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, device, *, seed_base: int = 0,
                 uncond_prompt: str = "", n_inference_steps: int = 50, cfg_scale: float = 7.5, height: int = 512,
                 width: int = 512, input_images: Optional[Sequence] = None, strength: float = 0.8, group=None,
-                gather_device=None, generate=None, streams_per_gpu: int = 1):
+                gather_device=None, generate=None, streams_per_gpu: int = 1, batch_per_gpu: int = 1, generate_batch=None):
     """Shard ``prompts`` over the ranks of the initialised process group (prompt i -> rank i mod N, seed =
     seed_base + i), run generate() per prompt, gather on rank 0.  Returns (images or None, stats).
 
     ``streams_per_gpu`` > 1: throughput mode -- this rank's prompts are dealt to that many LANES, each a thread running
     generate() on its own HIP stream over the shared packed weights (``lane_models``).  Every image is the same as in the
-    one-lane run (same seed, same kernels, same plans); only the wall time per BATCH of prompts changes."""
+    one-lane run (same seed, same kernels, same plans); only the wall time per BATCH of prompts changes.
+
+    ``batch_per_gpu`` > 1 (txt2img only): this rank's prompts go through ``pipeline.generate_batch`` in groups of that many
+    -- ONE chain of launches at UNet batch 2 x group, the weights streamed once per step for the whole group -- instead of
+    overlapping several latency-bound chains.  Prompt i keeps its seed ``seed_base + i`` and its own noise stream."""
     import threading
     import time
 
     import torch.distributed as dist
     if generate is None:
         from .pipeline import generate
+    batch_per_gpu = max(1, int(batch_per_gpu))
+    if batch_per_gpu > 1:
+        if input_images is not None:
+            raise ValueError("run_prompts: batch_per_gpu > 1 is txt2img only")
+        if generate_batch is None:
+            from .pipeline import generate_batch
+        streams_per_gpu = 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     todo = shard_prompts(list(enumerate(prompts)), rank, world)
@@ -248,6 +259,18 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     results: Dict[int, torch.Tensor] = {}
     per_image: Dict[int, float] = {}
     errors: List[BaseException] = []
+
+    def work_batched():
+        for g0 in range(0, len(todo), batch_per_gpu):
+            grp = todo[g0:g0 + batch_per_gpu]
+            t1 = time.perf_counter()
+            imgs = generate_batch(prompts=[p for _, p in grp], uncond_prompt=uncond_prompt, seeds=[seed_base + i for i, _ in grp],
+                                  do_cfg=True, cfg_scale=cfg_scale, sampler_name="ddpm", n_inference_steps=n_inference_steps,
+                                  models=models, device=device, idle_device=None, tokenizer=tokenizer, height=height, width=width)
+            dt = (time.perf_counter() - t1) / len(grp)
+            for (i, _), im in zip(grp, imgs):
+                results[i] = torch.from_numpy(im)
+                per_image[i] = dt
 
     def work(lane: int):
         stream = torch.cuda.Stream(device=device) if (on_gpu and n_lanes > 1) else None
@@ -269,7 +292,9 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     if dist.is_initialized():
         dist.barrier(group)
     t0 = time.perf_counter()
-    if n_lanes == 1:
+    if batch_per_gpu > 1:
+        work_batched()
+    elif n_lanes == 1:
         work(0)
     else:
         threads = [threading.Thread(target=work, args=(k,), name=f"sdmi-lane-{k}") for k in range(n_lanes)]
@@ -284,7 +309,7 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     mine = [results[i] for i, _ in todo]
     elapsed = max_over_ranks(time.perf_counter() - t0, device=gather_device, group=group)
     images = gather_image_lists(mine, len(prompts), (height, width, 3), device=gather_device, group=group)
-    stats = {"n_prompts": len(prompts), "world": world, "streams_per_gpu": n_lanes, "elapsed_s": elapsed,
+    stats = {"n_prompts": len(prompts), "world": world, "streams_per_gpu": n_lanes, "batch_per_gpu": batch_per_gpu, "elapsed_s": elapsed,
              "images_per_s": len(prompts) / elapsed if elapsed > 0 else 0.0,
              "rank0_s_per_image": [per_image[i] for i, _ in todo]}
     return images, stats
@@ -319,6 +344,8 @@ def _main(argv=None) -> int:
     ap.add_argument("--out-dir", default=None)
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="throughput mode: this many concurrent generate() lanes per GPU over one copy of the packed weights")
+    ap.add_argument("--batch-per-gpu", type=int, default=1,
+                    help="throughput mode: groups of this many prompts per GPU go through ONE batched denoising loop (txt2img)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs")
     args = ap.parse_args(argv)
     if bool(args.ckpt) == bool(args.synthetic):
@@ -365,7 +392,7 @@ def _main(argv=None) -> int:
 
     images, stats = run_prompts(prompts, models, tokenizer, dev, seed_base=args.seed_base, n_inference_steps=args.steps,
                                 cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=dev,
-                                streams_per_gpu=args.streams_per_gpu)
+                                streams_per_gpu=args.streams_per_gpu, batch_per_gpu=args.batch_per_gpu)
     if rank == 0:
         if args.out_dir:
             from PIL import Image

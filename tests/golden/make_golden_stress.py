@@ -11,7 +11,8 @@ shipped), loads the synthetic weights into the reference's own nn.Modules and re
   stress_meta.json per block: rel-L2 of the reference module itself run in torch-CPU fp16 against its fp32 output (the
                    yardstick: what fp16 storage alone costs under this law), thread count, torch version
 
-usage: make_golden_stress.py [blocks] [full] [e2e]     (default: all)
+usage: make_golden_stress.py [blocks] [full] [e2e] [e2e50]     (default: blocks full e2e)
+  stress_e2e50.npz the same generate() at BASELINE configs[1]'s own 50 steps
 """
 import json
 import os
@@ -118,7 +119,7 @@ class Tap(torch.nn.Module):
 
 
 @torch.no_grad()
-def e2e(unet_mod):
+def e2e(unet_mod, steps=20):
     import clip as ref_clip
     import decoder as ref_dec
     import diffusion as ref_diff
@@ -135,11 +136,17 @@ def e2e(unet_mod):
     unet, dect = Tap(unet_mod, keep=True), Tap(dec)
     t0 = time.time()
     img = ref_pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True,
-                                cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=20,
+                                cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=steps,
                                 models={"clip": clip, "diffusion": unet, "decoder": dect}, seed=42, device="cpu",
                                 idle_device=None, tokenizer=StubTokenizer())
-    print(f"  stress txt2img 20 steps: {time.time()-t0:.1f}s", flush=True)
+    print(f"  stress txt2img {steps} steps: {time.time()-t0:.1f}s", flush=True)
     lat_in = torch.cat(unet.inputs)
+    if steps != 20:
+        # BASELINE configs[1]'s own step count under the stress law: the uint8 image, the decoder's float image at FULL
+        # resolution (fp16: 1.5 MB) and the latents entering every 5th step
+        np.savez_compressed(os.path.join(HERE, f"stress_e2e{steps}.npz"), u8=img, float16=dect.last[0].half().numpy(),
+                            latents=dect.last_in.numpy(), lat_every5=lat_in[::5].numpy(), threads=np.array(torch.get_num_threads()))
+        return
     np.savez_compressed(os.path.join(HERE, "stress_e2e.npz"),
                         txt20_u8=img, txt20_float=dect.last[0, :, ::4, ::4].numpy(), txt20_latents=dect.last_in.numpy(),
                         txt20_lat_every5=lat_in[::5].numpy(),
@@ -209,6 +216,8 @@ def main():
         json.dump(meta, open(mpath, "w"), indent=1)
     if "e2e" in which:
         e2e(unet_mod)
+    if "e2e50" in which:
+        e2e(unet_mod, steps=50)
 
 
 if __name__ == "__main__":

@@ -291,3 +291,30 @@ def test_run_prompts_lanes_do_not_leak_device_memory(models):
     with pytest.raises(RuntimeError):
         lane.load_state_dict(unet.state_dict())
     unet.release_lanes()
+
+
+def test_generate_batch_matches_single_prompt_runs(models):
+    """pipeline.generate_batch: two prompts through ONE batched loop (UNet batch 4: cat([cond_0, cond_1, uncond_0, uncond_1]),
+    sdmi_unet_denoise_step_batch) give each prompt the image its own generate() call gives it -- same seed, same noise stream,
+    same CLIP / VAE -- up to the tile plans of the larger GEMMs; prompt 0 is the reference golden's prompt and is also checked
+    against the reference's own image with the single-prompt bounds."""
+    from pytorch_stable_diffusion_amd import pipeline
+    g = H.load_npz("e2e.npz")
+    m = dict(models)
+    m["decoder"] = models["decoder"].inner
+    kw = dict(do_cfg=True, cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=20, models=m, device=DEV, idle_device=None,
+              tokenizer=StubTokenizer())
+    prompts, seeds = ["a dog", "a red car by the sea"], [42, 7]
+    got = pipeline.generate_batch(prompts, uncond_prompt="", seeds=seeds, **kw)
+    assert len(got) == 2 and got[0].shape == (512, 512, 3) and got[0].dtype == np.uint8
+    for p, s, im in zip(prompts, seeds, got):
+        one = pipeline.generate(prompt=p, uncond_prompt="", input_image=None, strength=0.8, seed=s, **kw)
+        d = np.abs(im.astype(np.int32) - one.astype(np.int32))
+        G.log_metric(test="generate_batch", prompt=p, u8_max=int(d.max()), u8_mean=float(d.mean()))
+        # two fp16 paths with different summation orders (tile plans of the M = 16384 GEMMs): each sits ~6e-4 from the reference
+        # with rounding errors that the 20 steps decorrelate, so they are ~sqrt(2) x that apart (measured 8.1e-4, max 2 LSB)
+        assert d.max() <= U8_MAX and d.mean() / 255.0 < 1.5 * PIXEL_MAE, f"{p}: batched vs single uint8 max diff {d.max()}, mean {d.mean():.3f}"
+    d0 = np.abs(got[0].astype(np.int32) - g["txt2img_u8"].astype(np.int32))
+    assert d0.max() <= U8_MAX and d0.mean() / 255.0 < PIXEL_MAE, f"prompt 0 vs the reference: max {d0.max()}, MAE {d0.mean() / 255:.2e}"
+    with pytest.raises(ValueError):
+        pipeline.generate_batch(["a"] * 9, seeds=list(range(9)), **kw)

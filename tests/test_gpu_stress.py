@@ -275,3 +275,64 @@ def test_stress_e2e_txt2img_20_steps():
     yard = _meta().get("e2e20_ref_fp16", {"pixel_mae": 2.858e-3, "u8_max_diff": 10})
     G.log_metric(test="stress_e2e20", pixel_mae=mae, u8_max_diff=mx, ref_fp16_mae=yard["pixel_mae"], ref_fp16_u8=yard["u8_max_diff"])
     assert mae < 0.75 * yard["pixel_mae"] and mx <= 6, f"pixel MAE {mae:.2e} (torch-CPU fp16 reference: {yard['pixel_mae']:.2e}), uint8 max diff {mx}"
+
+
+def test_stress_per_block_attribution(stress_unet):
+    """Where the stress-law error comes from: every stage op of the UNet (ResBlock / AttentionBlock / down / up conv / output
+    layer; sd/diffusion.py:543-626,714-748) is run ALONE on the HIP path (sdmi_unet_run_block) on the ORACLE's input for that
+    op -- one oracle forward at 64x64, t = 980, traced -- and compared with the oracle's output of the same op.  The table
+    (rel-L2 of the whole output, and of the op's own contribution y - x where it adds its input back) goes to
+    gpurun_out/stress_attribution.json / profiles/; asserted: no op above 3x the worst the fixture blocks measure, and the
+    per-op errors, root-sum-squared along the chain with the skip structure ignored, stay in the range of the whole-UNet error."""
+    from oracle import ddpm_ref, unet_ref
+    from pytorch_stable_diffusion_amd import arch, synth
+    sd = synth.synth_state_dict(arch.diffusion_manifest(), law="stress")
+    lat = H.seeded((1, 4, 64, 64), 0).repeat(2, 1, 1, 1)
+    ctx = H.seeded((2, 77, 768), 1)
+    temb = ddpm_ref.time_embedding(980)
+    unet_ref.TRACE = []
+    try:
+        with torch.no_grad():
+            time_vec = unet_ref.time_mlp(sd, temb)
+            body = unet_ref.unet_body(sd, lat, ctx, time_vec)
+            eps_ref = unet_ref.output_layer(sd, body)
+        trace = unet_ref.TRACE
+    finally:
+        unet_ref.TRACE = None
+    h = stress_unet.handle()
+    stress_unet.set_context(ctx.to(DEV))
+    tv = time_vec.to(DEV)
+    rows = []
+    prev_c = 4
+    for p, op, x_in, x_out in trace:
+        cin = x_in.shape[1]
+        x1 = None
+        if op[0] == "res" and cin != prev_c and p.startswith("unet.decoders") and p.endswith(".0"):
+            x0, x1 = x_in[:, :prev_c], x_in[:, prev_c:]            # cat(x, skip): sd/diffusion.py:671
+        else:
+            x0 = x_in
+        prev_c = x_out.shape[1]
+        if op[0] == "conv" and op[1] == 4:
+            continue                                               # the 4 -> 320 stem reads NCHW latents (covered by the full forward)
+        kind, arg = {"res": (0, 1), "attn": (1, 1), "up": (2, 1), "conv": (3, op[3] if op[0] == "conv" else 1)}[op[0]]
+        oshape = (x_out.shape[0], x_out.shape[2], x_out.shape[3], x_out.shape[1])
+        got = h.run_block(p, kind, _nhwc(x0).to(DEV), None if x1 is None else _nhwc(x1).to(DEV), time=tv if kind == 0 else None,
+                          arg=arg, out_shape=oshape).permute(0, 3, 1, 2).cpu()
+        rel = H.rel_l2(got, x_out)
+        drel = H.rel_l2(got - x_in, x_out - x_in) if (x_out.shape == x_in.shape and x1 is None) else None
+        rows.append(dict(op=p, kind=op[0], shape=list(x_out.shape), rel_l2=rel, delta_rel_l2=drel, out_rms=float(x_out.square().mean().sqrt()),
+                         launches=h.last_launch_count))
+    got = h.run_block("final", 4, _nhwc(body).to(DEV), out_shape=tuple(eps_ref.shape)).cpu()
+    rows.append(dict(op="final", kind="out", shape=list(eps_ref.shape), rel_l2=H.rel_l2(got, eps_ref), delta_rel_l2=None,
+                     out_rms=float(eps_ref.square().mean().sqrt()), launches=h.last_launch_count))
+    full = stress_unet(lat.to(DEV), ctx.to(DEV), temb.to(DEV)).cpu()
+    full_rel = H.rel_l2(full, eps_ref)
+    out = dict(weights="synth law=stress", latent="64x64, t=980", full_unet_rel_l2=full_rel, ops=rows)
+    os.makedirs(G.OUT, exist_ok=True)
+    with open(os.path.join(G.OUT, "stress_attribution.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    worst = sorted(rows, key=lambda r: -r["rel_l2"])[:5]
+    G.log_metric(test="stress_attribution", full_unet_rel_l2=full_rel, worst=[(r["op"], r["rel_l2"]) for r in worst])
+    assert len(rows) >= 40
+    for r in rows:
+        assert r["rel_l2"] < 2.7e-3, f"{r['op']}: rel L2 {r['rel_l2']:.2e}"

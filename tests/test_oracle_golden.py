@@ -146,3 +146,15 @@ def test_quirk_q2_gate_is_dead():
     sd[prefix + ".linear_geglu_1.weight"][1280:] = 123.0
     y1 = unet_ref.attention_block(sd, prefix, x, ctx, 8)
     assert torch.equal(y0, y1)
+
+
+def test_oracle_stage_tables_match_the_product():
+    """The oracle restates the UNet graph itself (oracle/unet_ref.py ENCODERS / BOTTLENECK / DECODERS, from sd/diffusion.py:543-626)
+    instead of importing the product's stage tables; the two copies must agree (and the full-UNet goldens captured from the
+    imported reference pin both against the reference's own module tree)."""
+    from oracle import unet_ref
+    from pytorch_stable_diffusion_amd import arch
+    norm = lambda t: [[tuple(op) for op in st] for st in t]
+    assert norm(unet_ref.ENCODERS) == norm(arch.ENCODERS)
+    assert [tuple(op) for op in unet_ref.BOTTLENECK] == [tuple(op) for op in arch.BOTTLENECK]
+    assert norm(unet_ref.DECODERS) == norm(arch.DECODERS)

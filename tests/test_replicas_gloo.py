@@ -199,3 +199,31 @@ def test_lane_error_is_raised_on_the_caller():
 
     with pytest.raises(ValueError, match="lane failure"):
         replicas.run_prompts(_PROMPTS, _stub_models(_stub_weights()), StubTokenizer(), "cpu", generate=boom, streams_per_gpu=2)
+
+
+def test_batch_per_gpu_groups_keep_prompt_order_and_seeds():
+    """run_prompts(batch_per_gpu=2): the rank's prompts go to generate_batch in groups of two (the last group may be smaller)
+    with their own seeds seed_base + i; the images come back in prompt order and equal the one-by-one run (CPU stub: the grouping
+    and ordering plumbing; the batched HIP loop has its own GPU test)."""
+    from tests.stub_tokenizer import StubTokenizer
+    models = _stub_models(_stub_weights())
+    calls = []
+
+    def stub_batch(prompts, uncond_prompt="", seeds=None, models=None, tokenizer=None, n_inference_steps=3, height=64, width=64,
+                   cfg_scale=7.5, **_):
+        calls.append((list(prompts), list(seeds)))
+        return [_stub_generate(prompt=p, uncond_prompt=uncond_prompt, models=models, seed=s, tokenizer=tokenizer,
+                               n_inference_steps=n_inference_steps, height=height, width=width, cfg_scale=cfg_scale)
+                for p, s in zip(prompts, seeds)]
+
+    one, _ = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64, width=64,
+                                  generate=_stub_generate)
+    two, st = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64, width=64,
+                                   generate=_stub_generate, generate_batch=stub_batch, batch_per_gpu=2)
+    assert st["batch_per_gpu"] == 2 and st["streams_per_gpu"] == 1
+    assert calls == [(_PROMPTS[0:2], [100, 101]), (_PROMPTS[2:4], [102, 103]), (_PROMPTS[4:5], [104])]
+    assert len(one) == len(two) == len(_PROMPTS)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", generate_batch=stub_batch, batch_per_gpu=2, input_images=[None] * 5)
