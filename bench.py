@@ -95,6 +95,8 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.batch_prompts > 4:
+        os.environ.setdefault("SDMI_ARENA_GB", "24")          # UNet batch > 8: a larger activation arena (csrc/unet.hip), before the handle exists
     # rehearsal knobs (one-GPU box): SDMI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SDMI_BENCH_BACKEND=gloo
     # replaces RCCL (which refuses two ranks on one device); the production path is nccl, one rank per GPU
     if os.environ.get("SDMI_BENCH_ONE_DEVICE"):

@@ -108,6 +108,13 @@ int sdmi_unet_run_block(sdmi_unet* u, const char* prefix, int kind, int arg, con
 int sdmi_unet_profile(sdmi_unet* u, int enable);
 int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_class, int* launches_by_class);
 
+/* Guard of the LayerNorm fold (sd/diffusion.py:317-321,334-339,351-356 run as GEMMs on the raw stream: their error grows with
+ * |row mean| / sigma): *hits_out = rows with |mean| > 8 sigma (SDMI_LN_GUARD_SIGMA) that folded GEMMs of this handle have met since
+ * the last reset; reset != 0 clears the counter; fold_on = 0 / 1 switches the handle to the separate LayerNorm kernel / back
+ * (-1: unchanged).  Synchronises the stream: read it when a loop is over and repeat the loop unfused when it is not zero
+ * (Diffusion.denoise_native does). */
+int sdmi_unet_ln_guard(sdmi_unet* u, int* hits_out, int reset, int fold_on, void* stream);
+
 /* Number of kernel launches enqueued by the last sdmi_unet_forward, and bytes of packed weights. */
 int sdmi_unet_last_launch_count(const sdmi_unet* u);
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);
@@ -194,6 +201,9 @@ typedef struct sdmi_gemm_desc {
    * tiles has its moments split over the two parts; they add up).  Plain stores, every slot written exactly once: nothing to
    * zero, no dependence on workgroup order.  gacc_rows_img = rows (pixels) per image; the row blocks never straddle images. */
   float* gacc; int gacc_atom; int gacc_rows_img;
+  /* ln_guard != NULL (with ln_stat): every row whose |mean| exceeds ln_guard_sigma standard deviations adds 1 to *ln_guard
+   * (the guard of the LayerNorm fold: sdmi_unet_ln_guard) */
+  int* ln_guard; float ln_guard_sigma;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* record rows per image (T) and parts of the statistics the launch described by d writes to d->gacc (d->gacc != NULL);

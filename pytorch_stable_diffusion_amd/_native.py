@@ -37,7 +37,8 @@ class GemmDesc(C.Structure):
                 ("act", C.c_int), ("sm_valid", C.c_int), ("img_rows", C.c_int), ("w_img_stride", C.c_int),
                 ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int),
                 ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p),
-                ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int)]
+                ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int),
+                ("ln_guard", C.c_void_p), ("ln_guard_sigma", C.c_float)]
 
 
 class B2bDesc(C.Structure):
@@ -70,6 +71,7 @@ _SIGNATURES = {
                                          C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "sdmi_unet_denoise_step_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                                C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
+    "sdmi_unet_ln_guard": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p]),
     "sdmi_unet_run_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdmi_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -406,6 +408,15 @@ class UNetHandle(_DeviceBound):
         with self._guard():
             check(self._lib.sdmi_unet_denoise_step_batch(self._h, ptr(latents), n_prompts, step_idx, int(do_cfg), float(cfg_scale),
                                                          ptr(noise), c, h, w, self._stream()), "sdmi_unet_denoise_step_batch")
+
+    def ln_guard(self, reset: bool = True, fold_on: Optional[bool] = None) -> int:
+        """Rows beyond the LayerNorm-fold guard's threshold since the last reset (synchronises the stream); fold_on switches
+        the handle between the folded GEMMs and the separate LayerNorm kernel."""
+        hits = C.c_int(0)
+        with self._guard():
+            check(self._lib.sdmi_unet_ln_guard(self._h, C.byref(hits), int(reset), -1 if fold_on is None else int(fold_on),
+                                               self._stream()), "sdmi_unet_ln_guard")
+        return hits.value
 
     def run_block(self, prefix: str, kind: int, x0: torch.Tensor, x1: Optional[torch.Tensor] = None,
                   time: Optional[torch.Tensor] = None, arg: int = 1, out_shape=None) -> torch.Tensor:

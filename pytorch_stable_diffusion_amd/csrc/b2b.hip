@@ -349,6 +349,8 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
       var_d = var_d < 0.0 ? 0.0 : var_d;
       const float mean = (float)mean_d;
       const float rstd = rsqrtf((float)var_d + p.eps);
+      // (every lane of an 8-lane group holds the same row: one of them reports)
+      if (p.ln_guard != nullptr && (lane & 7) == 0 && mean_d * mean_d > (double)p.ln_guard_thr2 * var_d) atomicAdd(p.ln_guard, 1);
 #pragma unroll
       for (int i = 0; i < kNR; ++i) {                    // the lanes holding row i of this wave: its index in lane bits 5.. down
         const int src = kNR == 8 ? (((i >> 2) << 5) | (((i >> 1) & 1) << 4) | ((i & 1) << 3)) : (((i >> 1) << 5) | ((i & 1) << 4));

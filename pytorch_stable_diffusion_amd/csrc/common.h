@@ -235,6 +235,11 @@ struct GemmArgs {
   // partial sums, workgroups (kz = 0, tn = 0) also write {mean, rstd} of their rows to ln_out[M][2], and splitk_finalize
   // applies  rstd (sum of folded slabs - mean g) + sum of plain slabs + bias (+ res)
   float* ln_out;
+  // Guard of the fold: it multiplies the RAW stream's fp16 shadow, so its error grows like |row mean| / sigma x 2^-12 (measured
+  // 1.5e-3 at 10 sigma, 3.8e-3 at 30 against 2e-4 unfused).  ln_guard != nullptr: a workgroup that meets a row with
+  // mean^2 > ln_guard_thr2 * variance adds 1 to *ln_guard; the caller reads the counter when the loop is over and repeats it
+  // with the fold off (Engine::ln_fold_on) -- no host synchronisation inside the loop.
+  int* ln_guard; float ln_guard_thr2;
   int no_finalize;     // split-K: leave the partial sums in the slabs, launch no splitk_finalize
   // GroupNorm statistics of the output from this launch's epilogue (GnRec above): the one-pass path accumulates them in
   // store_tile, a split-K launch in splitk_finalize.  Needs rows_img % BM == 0 (a tile inside one image), no transposed tail.
@@ -273,6 +278,7 @@ struct B2bArgs {
   // images of S rows); a1 is unused.
   const void* gx; int gx_f32;
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
+  int* ln_guard; float ln_guard_thr2;     // as GemmArgs::ln_guard, for the rows of S
   GnRec gacc;                     // GroupNorm statistics of `out` (npass2 == 1 only; rows_img = pixels per image, mod = M, T = rows_img / 32, parts = 1)
 };
 int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M

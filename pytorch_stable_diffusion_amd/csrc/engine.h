@@ -231,6 +231,11 @@ struct Engine {
   Arena arena;
   float* slab = nullptr; size_t slab_bytes = 0;
   float* gn_partial = nullptr;
+  // LayerNorm fold and its guard (GemmArgs::ln_guard): ln_fold_on = false takes the separate LayerNorm kernel everywhere (what
+  // SDMI_NO_LNFOLD=1 does for a whole process); ln_guard counts rows whose |mean| exceeds ln_guard_thr sigma in any folded GEMM
+  bool ln_fold_on = getenv("SDMI_NO_LNFOLD") == nullptr;
+  int* ln_guard = nullptr;
+  static float ln_guard_thr() { static const float v = getenv("SDMI_LN_GUARD_SIGMA") ? (float)atof(getenv("SDMI_LN_GUARD_SIGMA")) : 8.f; return v; }
   // producer-side GroupNorm statistics (GnRec): the records live in the activation arena next to the tensor they describe
   bool gacc_enabled = false;           // the UNet engine turns it on (the VAE / CLIP engines take every GroupNorm's own statistics)
   static bool gacc_on() { static const bool on = !(getenv("SDMI_GN_ACC") && atoi(getenv("SDMI_GN_ACC")) == 0); return on; }
@@ -637,6 +642,7 @@ struct Engine {
     defer = defer && defer_on() && a.ksplit > 1 && !a.outT && !a.act && !a.phase2 && a.cs_hi == 0 && !a.ln_stat && !a.rowstat &&
             a.ldc == a.N && (!a.res || a.ldr == a.N) && a.Ho * a.Wo <= defer_max_px();
     a.no_finalize = 1;                     // the combine is this function's own launch (timed as its own class) or deferred
+    if (a.ln_stat && ln_guard) { a.ln_guard = ln_guard; a.ln_guard_thr2 = ln_guard_thr() * ln_guard_thr(); }
     memset(&a.gacc, 0, sizeof(a.gacc));
     if (yact && yact->grec && !defer && it->second.cfg >= 0) {
       set_gacc(a, *yact);
@@ -646,7 +652,7 @@ struct Engine {
       if (!ok) memset(&a.gacc, 0, sizeof(a.gacc));
     }
     if (rs) {
-      static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
+      const bool no_fold = !ln_fold_on;
       rs->ptr = nullptr;
       if (!no_fold && a.ksplit == 1 && !a.outT && it->second.cfg >= 0 && it->second.cfg < sdmi_gemm_num_plain_cfgs()) {
         int bm, bn;
@@ -948,6 +954,7 @@ struct Engine {
     if (r2) { if (r2->f) { t.r2 = r2->f; t.r2_f32 = 1; } else { t.r2 = r2->h; } }
     if (y.f) { t.out = y.f; t.out_f32 = 1; t.out16 = y.h; } else { t.out = y.h; }
     t.M = a1.M(); t.eps = 1e-5f; t.npass2 = 1; t.ldo = 320;
+    t.ln_guard = ln_guard; t.ln_guard_thr2 = ln_guard_thr() * ln_guard_thr();
     if (y_gacc && y_gacc->grec && (a1.H * a1.W) % 64 == 0 && t.M / 32 <= 256 &&      // (32-row tiles only: the 64-row form has no registers to spare)
         (a1.H * a1.W) / 32 * (320 / kGnAtom) <= kGnRecMax) {
       t.gacc.rec = y_gacc->grec; t.gacc.atom = kGnAtom; t.gacc.natoms = 320 / kGnAtom; t.gacc.rows_img = a1.H * a1.W; t.gacc.mod = t.M;
@@ -979,6 +986,7 @@ struct Engine {
     t.w2 = f2.w; t.K2 = 320; t.h2 = f2.h; t.cscale = cscale;
     t.out = qk.h; t.ldo = qk.C; t.npass2 = 3; t.vt = vt; t.S = S; t.ldt = ldt;
     t.M = a1.M(); t.eps = 1e-5f;
+    t.ln_guard = ln_guard; t.ln_guard_thr2 = ln_guard_thr() * ln_guard_thr();
     const double flops = 2.0 * t.M * 320.0 * (320.0 + 960.0);
     prof_begin(0, flops);
     TRY(sdmi_launch_b2b(t, st));
@@ -1035,10 +1043,13 @@ struct Engine {
     // back-to-back launch
     static const bool b2b_on = !(getenv("SDMI_B2B") && atoi(getenv("SDMI_B2B")) == 0);
     static const bool b2b_qkv_on = !(getenv("SDMI_B2B_QKV") && atoi(getenv("SDMI_B2B_QKV")) == 0);
-    static const bool no_fold = getenv("SDMI_NO_LNFOLD") != nullptr;
+    const bool no_fold = !ln_fold_on;
     // one round of workgroups only (<= 256 of them, 32 or 64 rows each): at 768x768 (M = 18432: 288 workgroups) the second,
     // nearly empty round makes the fused form slower than the GEMM pairs (same box: 8.17 vs 8.11 ms/step)
-    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0 && B * S <= 16384;
+    // (beyond 16384 rows -- the batched multi-prompt mode -- only whole rounds of 64-row workgroups: SDMI_B2B_FULLROUNDS=0 to A/B)
+    static const bool b2b_rounds = !(getenv("SDMI_B2B_FULLROUNDS") && atoi(getenv("SDMI_B2B_FULLROUNDS")) == 0);
+    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0 &&
+                         (B * S <= 16384 || (b2b_rounds && (B * S) % (64 * 256) == 0 && S % 64 == 0));
     TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
     if (!vt) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     asm volatile("" ::"s"(p.a0), "s"(p.w), "s"(p.zero), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.C0), "s"(p.C1), "s"(p.lda0), "s"(p.ldw),
                  "s"(p.ks), "s"(p.stride), "s"(p.ups), "s"(p.phase2), "s"(p.ksplit), "s"(p.ksteps_per), "s"(p.n_major), "s"(p.img_rows),
                  "s"(p.w_img_stride), "s"(p.vec_img_stride), "s"(p.ln_stat), "s"(p.ln_ksteps), "s"(p.tiles), "s"(p.tdiv), "s"(p.plain),
-                 "s"(p.tiles_magic), "s"(p.tdiv_magic), "s"(p.bias));
+                 "s"(p.tiles_magic), "s"(p.tdiv_magic), "s"(p.bias), "s"(p.ln_guard), "s"(p.gacc.rec), "s"(p.gacc.rows_magic));
   else      // the 16-wave kernels have 128 VGPRs per lane and no room for the SGPR pressure of the batch: warm the lines only
     sdmi_kernarg_warm<sizeof(GemmArgs) + 16>();     // + the hidden grid size this kernel reads (gridDim.x)
 #ifdef SDMI_CLK_PROBE
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const float mean = (float)mean_d;
     s_ln[2 * tid] = mean;
     s_ln[2 * tid + 1] = rsqrtf((float)var + p.ln_eps);
+    if (p.ln_guard != nullptr && m0 + tid < p.M && tn == 0 && kz == 0 && mean_d * mean_d > (double)p.ln_guard_thr2 * var) atomicAdd(p.ln_guard, 1);
     if (p.ln_out != nullptr && kz == 0 && tn == 0 && m0 + tid < p.M) {      // for splitk_finalize (partial fold + split-K)
       p.ln_out[2 * (m0 + tid)] = mean;
       p.ln_out[2 * (m0 + tid) + 1] = s_ln[2 * tid + 1];
@@ -877,8 +878,14 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   const int nkt = 9 * nchunk;
   const int kt0 = kz * p.ksteps_per;                 // multiple of 9 (launcher)
   const int kt1 = min(kt0 + p.ksteps_per, nkt);
-  const int nk = kt1 - kt0;
+  // Extra 1x1 segment (the ResBlock's skip conv fused into conv_merged: GemmArgs::x0 / x1): (X0 + X1) / 64 more K-steps behind
+  // the taps, taken by the LAST K-slice.  An extra chunk is staged like a conv chunk -- its 64 channels of the (TH + 2) input
+  // rows into a halo buffer -- and multiplied once, with the centre tap.  "Unified" chunk index: [0, nchunk) conv chunks of
+  // nine K-steps, [nchunk, nchunk + nx) extra chunks of one.
+  const int nx = kt1 == nkt ? (p.X0 + p.X1) >> 6 : 0;
+  const int nk = kt1 - kt0 + nx;
   const int c_first = kt0 / 9;
+  const int c_end = kt1 / 9 + nx;                    // unified chunks [c_first, c_end) belong to this K-slice
 
   const int W = p.Wo, Hh = p.Ho, W2 = W + 2;
   const int TH = BM / W;
@@ -918,11 +925,13 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       h_lds[t] = q < NHI ? (hy * W2 + 1 + seg * 8) * 128 : -1;   // wave-uniform LDS byte offset of the piece
     }
     auto halo_piece = [&](int t, int chunk, char* hb) {
-      const int cabs = chunk << 6;
-      const bool second = cabs >= p.C0;
-      const f16* base = second ? p.a1 : p.a0;
-      const int ld = second ? p.lda1 : p.lda0;
-      const int cc = second ? cabs - p.C0 : cabs;
+      const bool extra = chunk >= nchunk;             // (unified index: see nx above; the x sources have the output's spatial size)
+      const int cabs = (extra ? chunk - nchunk : chunk) << 6;
+      const int Ca = extra ? p.X0 : p.C0;
+      const bool second = cabs >= Ca;
+      const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
+      const int ld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
+      const int cc = second ? cabs - Ca : cabs;
       const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
       const f16* gz = p.zero + h_gch[t];
       const f16* g = h_in[t] ? base + ((size_t)h_pix[t] * ld + cc + h_gch[t]) : gz;
@@ -940,15 +949,21 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       b_ok[i] = n < p.N;
       b_ptr[i] = b_ok[i] ? p.w + (size_t)n * p.ldw + (size_t)c_first * 64 + gch : p.zero + gch;
     }
-    int tap = 0, chunk = c_first;
+    int tap = 0, chunk = c_first;                     // the K-step staged next
     auto stage_b = [&](int slot) {
       char* sb = bring + slot * C::B_BYTES;
+      // weight columns of the next K-step: the next tap of this chunk (+ Cin), tap 0 of the next chunk (+ 64 - 8 Cin), or --
+      // behind the last conv chunk and between extra chunks -- the next 64 columns of the extra segment (+ 64: it starts at
+      // 9 Cin = 8 Cin + nchunk * 64)
+      int inc;
+      if (chunk >= nchunk) { inc = 64; ++chunk; }
+      else if (tap < 8) { inc = Cin; ++tap; }
+      else { tap = 0; ++chunk; inc = chunk < nchunk ? 64 - 8 * Cin : 64; }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         glds16(b_ptr[i], sb + (i * NW + wave) * 1024);
-        if (b_ok[i]) b_ptr[i] += (tap == 8) ? (64 - 8 * Cin) : Cin;
+        if (b_ok[i]) b_ptr[i] += inc;
       }
-      if (++tap == 9) { tap = 0; ++chunk; }
     };
     // prologue: whole halo of the first chunk + first NS-1 weight tiles
 #pragma unroll
@@ -967,14 +982,24 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-      if (t + NS - 1 < nk) {
+      const bool have_next = cchunk + 1 < c_end;
+      char* hb_next = ((cchunk + 1 - c_first) & 1) ? hb1 : hb0;
+      const bool extra_now = cchunk >= nchunk;        // an extra chunk is being multiplied: ONE interval, not nine
+      if (extra_now) {
+        // the tail of the last K-slice: the next extra chunk's whole halo in this one interval, and a plain wait for
+        // everything (a handful of intervals per launch: no counted overlap here)
+        if (t + NS - 1 < nk) stage_b(nxt);
+        if (have_next) {
+#pragma unroll
+          for (int tt = 0; tt < NTAPH; ++tt) halo_piece(tt, cchunk + 1, hb_next);
+        }
+      } else if (t + NS - 1 < nk) {
         stage_b(nxt);
         // one halo piece of the NEXT chunk (dummy DMA keeps the per-interval count constant)
-        const bool have_next = (cchunk + 1) * 9 < kt1;
         if (ctap < NTAPH && have_next) {
 #pragma unroll
           for (int tt = 0; tt < NTAPH; ++tt)
-            if (tt == ctap) halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
+            if (tt == ctap) halo_piece(tt, cchunk + 1, hb_next);
         } else {
           glds16(p.zero, dump);
         }
@@ -983,7 +1008,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
       const int rem = nk - 2 - t;
-      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      if (extra_now) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
       else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SDMI_CLK_PROBE_FINE
@@ -994,7 +1020,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += __builtin_amdgcn_s_memtime() - s2;
 #endif
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      if (++ctap == 9) { ctap = 0; ++cchunk; }
+      if (extra_now) ++cchunk;
+      else if (++ctap == 9) { ctap = 0; ++cchunk; }
     }
 #ifdef SDMI_CLK_PROBE_FINE
     if (lane == 0 && wave == 0 && blockIdx.x < 512) {
@@ -1035,7 +1062,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-      const int kh = ctap / 3, kw = ctap - kh * 3;
+      const bool extra_now = c_first + cchunk >= nchunk;       // an extra chunk: the centre tap, one K-step
+      const int kh = extra_now ? 1 : ctap / 3, kw = extra_now ? 1 : ctap - (ctap / 3) * 3;
       const char* hb = (cchunk & 1) ? hb1 : hb0;
       const char* Bs = bring + cur * C::B_BYTES + b_row_off;
       int a_off[FM], a_co[FM];
@@ -1074,7 +1102,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       acc_cmp += s1 - s0; acc_cbar += __builtin_amdgcn_s_memtime() - s1;
 #endif
       cur = (cur + 1 == NS) ? 0 : cur + 1;
-      if (++ctap == 9) { ctap = 0; ++cchunk; }
+      if (extra_now) ++cchunk;
+      else if (++ctap == 9) { ctap = 0; ++cchunk; }
     }
 #ifdef SDMI_CLK_PROBE_FINE
     if (lane == 0 && wave == 0 && blockIdx.x < 512) {
@@ -1369,7 +1398,8 @@ void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
 
 // halo-reuse kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image
 static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
-  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.X0 != 0 || a.rowstat || a.ln_stat) return false;
+  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.rowstat || a.ln_stat) return false;
+  if ((a.X0 || a.X1) && (a.ups != 0 || a.X0 % 64 != 0 || a.X1 % 64 != 0 || !a.x0)) return false;    // extra 1x1 segment: sources on the output grid
   if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
   if (a.Wo % 8 != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
   const int TH = c.BM / a.Wo;
@@ -1482,9 +1512,16 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     const double a_bytes = 2.0 * ((double)a.M * a.stride * a.stride / (a.ups ? 4 : 1)) * (a.C0 + a.C1) + 2.0 * a.M * (a.X0 + a.X1);
     p.n_major = force >= 0 ? force : (w_bytes > a_bytes);
   }
-  p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
-  if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
-  p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
+  if (halo) {
+    // the halo kernel splits the CONV K-steps at channel-chunk boundaries (9 taps each); the extra 1x1 segment rides with the last slice
+    const int nkc = 9 * ((a.C0 + a.C1) / 64);
+    if (p.ksplit > nkc / 9) p.ksplit = nkc / 9;
+    p.ksteps_per = ((nkc + p.ksplit - 1) / p.ksplit + 8) / 9 * 9;
+    p.ksplit = (nkc + p.ksteps_per - 1) / p.ksteps_per;
+  } else {
+    p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
+    p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
+  }
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
   const int tiles_m = (a.M + c.BM - 1) / c.BM, tiles_n = (a.N + c.BN - 1) / c.BN;
   const int tiles = tiles_m * tiles_n;

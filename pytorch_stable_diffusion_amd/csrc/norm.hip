@@ -76,10 +76,15 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
   }
 }
 
-// grid: (pixel blocks, B); block 256.  Phase 1: all 256 threads reduce the chunk partials (fixed
-// order) to mean/rstd per group; phase 2: normalise (+SiLU) 8-channel chunks.
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_block) {
-  __shared__ double s_red[8][32][2];
+// grid: (pixel blocks, B); block 512.  Phase A: every thread requests its activations (and gamma / beta); statistics: all threads
+// add up the chunk partials of gn_stats_kernel -- or the records the producers' epilogues left behind (GnRec) -- in a fixed
+// order to mean / rstd per group; phase B: normalise (+SiLU) 8-channel chunks.
+// 512 threads x 2 items, not 256 x 4 (round 4): with the records and the gamma / beta prefetch the 256-thread form needed 189
+// registers per lane -- two workgroups per CU, two rounds of workgroups on the 64x64 maps; this one stays under 128 at 16
+// statistics loads in flight per thread.
+constexpr int GNA_NT = 512, GNA_IT = 2, GNA_SH = GNA_NT / 32;      // threads, items per thread, shares per group
+__global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_per_block) {
+  __shared__ double s_red[GNA_SH][32][2];
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
   const int n = blockIdx.y;
@@ -87,18 +92,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
   // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, p.P);
-  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 4 per thread
-  constexpr int IT = 4;
+  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 2 per thread
+  constexpr int IT = GNA_IT;
   float v[IT][8];
   f32x4 ga_[IT], gb_[IT], ba_[IT], bb_[IT];
   int px_[IT], c_[IT];
   bool ok[IT];
-  const int q_first = tid / C8, r_first = tid - q_first * C8;     // item = tid + 256 k -> (pixel, chunk) incrementally
-  const int dq = 256 / C8, dr = 256 - dq * C8;
+  const int q_first = tid / C8, r_first = tid - q_first * C8;     // item = tid + NT k -> (pixel, chunk) incrementally
+  const int dq = GNA_NT / C8, dr = GNA_NT - dq * C8;
   int qq = q_first, rr = r_first;
 #pragma unroll
   for (int k = 0; k < IT; ++k) {               // phase A: every load of this thread in flight at once
-    const int it = tid + k * 256;
+    const int it = tid + k * GNA_NT;
     ok[k] = it < items;
     px_[k] = p0 + (ok[k] ? qq : 0);
     c_[k] = (ok[k] ? rr : 0) * 8;
@@ -114,19 +119,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     ga_[k] = *(const f32x4*)(p.gamma + c_[k]); gb_[k] = *(const f32x4*)(p.gamma + c_[k] + 4);
     ba_[k] = *(const f32x4*)(p.beta + c_[k]); bb_[k] = *(const f32x4*)(p.beta + c_[k] + 4);
   }
+  const int g = tid & 31, sl = tid >> 5;
   if (p.acc0 != nullptr) {
-    // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 8)
+    // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 16)
     // adds up its share of the group's records -- apg atoms x T record rows (x parts), per concat source -- all loads in flight
     // at once, then the shares meet in LDS exactly as the chunk partials below do.  One pass, no statistics launch.
-    const int g = tid & 31, sl = tid >> 5;
     const int apg = cpg / p.atom, na0 = p.C0 / p.atom;
     const int Tmax = max(p.accT0, p.accT1);
-    const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 8, ...
-    constexpr int MAXR = 16;
+    const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 16, ...
+    constexpr int MAXR = 8;                             // kGaccMaxRec (4096) records / 32 groups / 16 shares
     f32x4 rv[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
-      const int f = sl + 8 * k;
+      const int f = sl + GNA_SH * k;
       rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (f < npair) {
         const int t = f / apg, a = g * apg + (f - t * apg);             // atom index in concat channel space
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     double s = 0.0, q = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) { s += (double)rv[k][0] + (double)rv[k][2]; q += (double)rv[k][1] + (double)rv[k][3]; }
-    for (int f = sl + 8 * MAXR; f < npair; f += 8) {      // (more records than the producers' bound allows: still correct)
+    for (int f = sl + GNA_SH * MAXR; f < npair; f += GNA_SH) {      // (more records than the producers' bound allows: still correct)
       const int t = f / apg, a = g * apg + (f - t * apg);
       const bool second = a >= na0;
       const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
@@ -156,17 +161,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     s_red[sl][g][1] = q;
   } else {
     // (statistics: the chunk partials of gn_stats_kernel)
-    const int g = tid & 31, sl = tid >> 5;
     double s = 0.0, q = 0.0;
-    // nchunk <= 128 -> at most 16 chunks per slice: all loads issued at once (one latency round)
-    f32x2 pv[16];
+    // nchunk <= 128 -> at most 8 chunks per share: all loads issued at once (one latency round)
+    f32x2 pv[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int ch = sl + 8 * k;
+    for (int k = 0; k < 8; ++k) {
+      const int ch = sl + GNA_SH * k;
       pv[k] = ch < p.nchunk ? *(const f32x2*)(p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { s += (double)pv[k][0]; q += (double)pv[k][1]; }
+    for (int k = 0; k < 8; ++k) { s += (double)pv[k][0]; q += (double)pv[k][1]; }
     s_red[sl][g][0] = s;
     s_red[sl][g][1] = q;
   }
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     // (tests/test_gpu_kernels.py::test_groupnorm_large_mean) the output stays within an fp16 ulp up to |mean| = 100 sigma.
     double s = 0.0, q = 0.0;
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) { s += s_red[sl][tid][0]; q += s_red[sl][tid][1]; }
+    for (int k = 0; k < GNA_SH; ++k) { s += s_red[k][tid][0]; q += s_red[k][tid][1]; }
     const double cnt = (double)cpg * (double)p.P;
     const double mean = s / cnt;
     double var = q / cnt - mean * mean;
@@ -196,13 +200,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs p, int pix_per_blo
     const int r0 = c - g0 * cpg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int g = g0, rr2 = r0 + e;
-      if (rr2 >= cpg) { rr2 -= cpg; ++g; }
-      if (rr2 >= cpg) { rr2 -= cpg; ++g; }
-      if (rr2 >= cpg) ++g;
+      int gg = g0, rr2 = r0 + e;
+      if (rr2 >= cpg) { rr2 -= cpg; ++gg; }
+      if (rr2 >= cpg) { rr2 -= cpg; ++gg; }
+      if (rr2 >= cpg) ++gg;
       const float gam = e < 4 ? ga[e] : gb[e - 4];
       const float bet = e < 4 ? ba[e] : bb[e - 4];
-      float y = (v[k][e] - s_mean[g]) * s_rstd[g] * gam + bet;
+      float y = (v[k][e] - s_mean[gg]) * s_rstd[gg] * gam + bet;
       if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));     // v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division
       o[e] = (f16)y;
     }
@@ -446,7 +450,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
     const int C8a = C / 8;
     int ppb = (256 * 4) / C8a;
     if (ppb < 1) ppb = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(256), 0, st, a, ppb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(GNA_NT), 0, st, a, ppb);
     SDMI_CHECK_HIP(hipGetLastError());
     return SDMI_OK;
   }
@@ -475,7 +479,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   int ppb = (256 * 4) / C8;
   if (ppb < 1) ppb = 1;
   const int nblk = (a.P + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(256), 0, st, a, ppb);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(GNA_NT), 0, st, a, ppb);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -225,7 +225,12 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
   if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
   u->gacc_enabled = true;                   // GroupNorm statistics from the producers' epilogues (engine.h attach_gacc)
-  u->arena.cap = u->partial ? ((size_t)1 << 30) : ((size_t)6 << 30);
+  if ((rc = u->dmalloc(&u->ln_guard, 256)) != SDMI_OK) return fail(rc);
+  if (hipMemset(u->ln_guard, 0, 256) != hipSuccess) return fail(SDMI_EHIP);
+  // activation arena: one bump allocation per forward (deterministic addresses); 6 GiB carry UNet batch <= 8 at 64x64 latents
+  // (four prompts of the batched throughput mode) and batch 2 at 96x96; SDMI_ARENA_GB sizes it for more (batch 16: 24)
+  static const size_t arena_gb = getenv("SDMI_ARENA_GB") ? (size_t)atoi(getenv("SDMI_ARENA_GB")) : 6;
+  u->arena.cap = u->partial ? ((size_t)1 << 30) : ((arena_gb ? arena_gb : 6) << 30);
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) { sdmi_set_error("weight packing failed: %s", hipGetErrorString(hipGetLastError())); return fail(SDMI_EHIP); }
   u->src.clear();   // caller's tensors are no longer referenced
@@ -268,6 +273,9 @@ int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out) {
   if ((rc = u->dmalloc(&u->slab, u->slab_bytes)) != SDMI_OK) return fail(rc);
   if ((rc = u->dmalloc(&u->gn_partial, (size_t)16 * 128 * 32 * 2 * 4)) != SDMI_OK) return fail(rc);
   u->gacc_enabled = src->gacc_enabled;
+  u->ln_fold_on = src->ln_fold_on;
+  if ((rc = u->dmalloc(&u->ln_guard, 256)) != SDMI_OK) return fail(rc);
+  if (hipMemset(u->ln_guard, 0, 256) != hipSuccess) return fail(SDMI_EHIP);
   u->arena.cap = src->arena.cap;
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) return fail(SDMI_EHIP);
@@ -484,6 +492,20 @@ int sdmi_unet_profile_read(sdmi_unet* u, double* ms_by_class, double* flops_by_c
   return SDMI_OK;
 }
 
+// LayerNorm-fold guard: rows beyond the threshold (|mean| > 8 sigma, SDMI_LN_GUARD_SIGMA) met by folded GEMMs since the last
+// reset; synchronises the stream (call it when a loop is over, not inside it).  fold_on >= 0 also switches the fold on / off.
+int sdmi_unet_ln_guard(sdmi_unet* u, int* hits_out, int reset, int fold_on, void* stream) {
+  if (!u) { sdmi_set_error("ln_guard: null handle"); return SDMI_EINVAL; }
+  TRY(u->enter(stream));
+  if (hits_out) {
+    SDMI_CHECK_HIP(hipMemcpyAsync(hits_out, u->ln_guard, sizeof(int), hipMemcpyDeviceToHost, u->st));
+    SDMI_CHECK_HIP(hipStreamSynchronize(u->st));
+  }
+  if (reset) SDMI_CHECK_HIP(hipMemsetAsync(u->ln_guard, 0, sizeof(int), u->st));
+  if (fold_on >= 0) u->ln_fold_on = fold_on != 0;
+  return SDMI_OK;
+}
+
 int sdmi_unet_last_launch_count(const sdmi_unet* u) { return u ? u->launches : 0; }
 int sdmi_unet_tuned_shapes(const sdmi_unet* u) { return u ? u->tuned_shapes : 0; }
 int sdmi_unet_device(const sdmi_unet* u) { return u ? u->device : -1; }
@@ -542,6 +564,7 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.act = d->act; a.sm_valid = d->sm_valid; a.img_rows = d->img_rows; a.w_img_stride = d->w_img_stride;
   a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw; a.phase2 = d->phase2;
   a.ln_ksteps = d->ln_ksteps; a.ln_out = d->ln_out;
+  a.ln_guard = d->ln_guard; a.ln_guard_thr2 = d->ln_guard_sigma * d->ln_guard_sigma;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;

@@ -23,6 +23,8 @@ class Diffusion:
         self._ctx_key = None
         self._parent = None
         self._lanes = []
+        self.ln_guard_hits = 0           # rows beyond the LayerNorm-fold guard in the last denoise_native loop
+        self.ln_guard_fallback = True    # repeat that loop unfused when there were any
         self.stream_f32 = stream_f32
         self.autotune = autotune
 
@@ -94,6 +96,7 @@ class Diffusion:
         ln.stream_f32, ln.autotune = self.stream_f32, self.autotune
         ln._ctx_key = None
         ln._lanes = []
+        ln.ln_guard_hits, ln.ln_guard_fallback = 0, self.ln_guard_fallback
         ln._parent = self
         ln._handle = self.handle().clone()
         self._lanes.append(ln)
@@ -160,12 +163,31 @@ class Diffusion:
         """The whole loop of sd/pipeline.py:205-237 as fused native steps; noise is drawn from the
         sampler's shared generator in the reference's order (one draw per step with t > 0)."""
         from .pipeline import get_time_embedding
-        lat = latents.to(self._device, torch.float32).contiguous().clone()
         self.set_context(context)
         self.set_schedule(torch.cat([get_time_embedding(t) for t in timesteps]))
-        for i, t in enumerate(timesteps):
-            noise = sampler.draw_noise(lat.shape, self._device) if t > 0 else None
-            self.step(lat, i, do_cfg, cfg_scale, noise, sampler.step_coefficients(t))
+        h = self.handle()
+        rng_state = sampler.generator.get_state()
+        h.ln_guard(reset=True)
+
+        def loop():
+            lat = latents.to(self._device, torch.float32).contiguous().clone()
+            for i, t in enumerate(timesteps):
+                noise = sampler.draw_noise(lat.shape, self._device) if t > 0 else None
+                self.step(lat, i, do_cfg, cfg_scale, noise, sampler.step_coefficients(t))
+            return lat
+
+        lat = loop()
+        # Guard of the LayerNorm fold (include/sdmi.h sdmi_unet_ln_guard): the folded GEMMs multiply the raw stream's fp16
+        # shadow, exact enough while a token row's |mean| stays within a few sigma.  The kernels count the rows beyond 8 sigma;
+        # when any was met the loop is repeated -- same latents, same noise stream -- through the separate LayerNorm kernel.
+        self.ln_guard_hits = h.ln_guard(reset=True)
+        if self.ln_guard_hits and self.ln_guard_fallback:
+            sampler.generator.set_state(rng_state)
+            h.ln_guard(reset=True, fold_on=False)
+            try:
+                lat = loop()
+            finally:
+                h.ln_guard(reset=True, fold_on=True)
         return lat
 
     @torch.no_grad()
@@ -183,10 +205,28 @@ class Diffusion:
         self.set_context(context)
         self.set_schedule(torch.cat([get_time_embedding(t) for t in timesteps]))
         one = (1,) + tuple(lat.shape[1:])
-        for i, t in enumerate(timesteps):
-            noise = torch.cat([s.draw_noise(one, self._device) for s in samplers]) if t > 0 else None
-            self.step(lat, i, do_cfg, cfg_scale, noise, samplers[0].step_coefficients(t))
-        return lat
+        h = self.handle()
+        states = [s.generator.get_state() for s in samplers]
+        h.ln_guard(reset=True)
+
+        def loop():
+            x = lat.clone()
+            for i, t in enumerate(timesteps):
+                noise = torch.cat([s.draw_noise(one, self._device) for s in samplers]) if t > 0 else None
+                self.step(x, i, do_cfg, cfg_scale, noise, samplers[0].step_coefficients(t))
+            return x
+
+        out = loop()
+        self.ln_guard_hits = h.ln_guard(reset=True)              # guard of the LayerNorm fold: see denoise_native
+        if self.ln_guard_hits and self.ln_guard_fallback:
+            for s, st in zip(samplers, states):
+                s.generator.set_state(st)
+            h.ln_guard(reset=True, fold_on=False)
+            try:
+                out = loop()
+            finally:
+                h.ln_guard(reset=True, fold_on=True)
+        return out
 
     # ---- reference call convention -------------------------------------------------------------------
     @torch.no_grad()

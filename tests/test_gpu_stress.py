@@ -253,28 +253,88 @@ def test_stress_full_unet_vs_golden(stress_unet):
     assert rel < 4e-3, f"rel L2 {rel:.2e}"
 
 
-def test_stress_e2e_txt2img_20_steps():
-    """pipeline.generate() with the stress-law UNet (benign CLIP / VAE decoder), 512x512, 20 steps, CFG 7.5, seed 42,
-    against the reference's own generate() on the CPU.  Under this law fp16 OPERANDS alone cost more than north_star's
-    1e-3: the reference's own UNet run in torch-CPU fp16 lands at 2.86e-3 / uint8 diff 10 (stress_meta.json
-    e2e20_ref_fp16), the native path at 1.59e-3 / 4 with every fold on and at 1.73e-3 .. 1.80e-3 with the LayerNorm
-    fold, the folded cross-attention or the back-to-back kernel switched off (same box, SDMI_NO_LNFOLD / SDMI_XATTN_FOLD=0 /
-    SDMI_B2B=0): the algebra removes fp16 roundings, it does not add error.  Asserted: below 3/4 of the fp16 yardstick."""
-    from pytorch_stable_diffusion_amd import arch, model_loader, pipeline, synth
-    from pytorch_stable_diffusion_amd.tokenizer import StubTokenizer
-    gold = np.load(os.path.join(H.GOLDEN, "stress_e2e.npz"))
+def _floor(steps):
+    """tests/golden/stress_floor.py: pixel MAE of the ORACLE (fp32 arithmetic) through the same loop with one operand class
+    stored in fp16 -- what fp16 storage alone costs under this law, whatever the kernels do"""
+    with open(os.path.join(H.GOLDEN, "stress_floor.json" if steps == 20 else f"stress_floor{steps}.json")) as f:
+        return {k: v["pixel_mae"] for k, v in json.load(f)["runs"].items()}
+
+
+def _stress_models():
+    from pytorch_stable_diffusion_amd import arch, model_loader, synth
     sds = model_loader.synthetic_state_dicts(("clip", "decoder", "encoder"))
     sds["diffusion"] = synth.synth_state_dict(arch.diffusion_manifest(), law="stress")
-    models = model_loader.preload_models_from_state_dicts(sds, DEV)
+    return model_loader.preload_models_from_state_dicts(sds, DEV)
+
+
+# Stated tolerance.  north_star's pixel MAE < 1e-3 is met on the benign law at BASELINE's own step counts (tests/test_gpu_e2e.py).
+# Under the STRESS law it is not reachable by ANY path that hands fp16 operands to the matrix cores: the oracle itself (fp32
+# arithmetic, pinned to the reference) with only the activation operand of every conv / linear rounded to fp16 lands at
+# 1.59e-3 @20 steps, with weights + activations + attention operands in fp16 at 1.40e-3 (weights alone 4.7e-4, attention
+# operands alone 3.5e-5; tests/golden/stress_floor.json, script beside it) -- and the per-op attribution
+# (test_stress_per_block_attribution, profiles/r04_stress_attribution.json) shows no dominant layer: every one of the 45 stage
+# ops adds 1.6e-4 .. 6.7e-4.  The HIP path measures 1.59e-3 .. 1.78e-3 / 4-6 LSB @20 (two builds whose single UNet forward is
+# equally far from the reference, 1.40e-3 and 1.41e-3 rel-L2: the 20 steps amplify WHICH roundings are made, the two floor runs
+# differ by as much): AT that floor.  Asserted: within 1.25x the larger fp16-activation floor (and the uint8 image within 6
+# LSB); the torch-CPU fp16 reference sits at 2.86e-3 / 10 LSB.
+STRESS_FLOOR_MARGIN = 1.25
+
+
+def _floor_bound(fl):
+    return STRESS_FLOOR_MARGIN * max(fl["weights + activations + attention fp16"], fl["activation operands fp16"])
+
+
+def test_stress_e2e_txt2img_20_steps():
+    """pipeline.generate() with the stress-law UNet (benign CLIP / VAE decoder), 512x512, 20 steps, CFG 7.5, seed 42,
+    against the reference's own generate() on the CPU."""
+    from pytorch_stable_diffusion_amd import pipeline
+    from pytorch_stable_diffusion_amd.tokenizer import StubTokenizer
+    gold = np.load(os.path.join(H.GOLDEN, "stress_e2e.npz"))
     img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True, cfg_scale=7.5,
-                            sampler_name="ddpm", n_inference_steps=20, models=models, seed=42, device=DEV, idle_device=None,
+                            sampler_name="ddpm", n_inference_steps=20, models=_stress_models(), seed=42, device=DEV, idle_device=None,
                             tokenizer=StubTokenizer())
     ref = gold["txt20_u8"]
     mae = float(np.abs(img.astype(np.float64) - ref.astype(np.float64)).mean() / 255.0)
     mx = int(np.abs(img.astype(np.int32) - ref.astype(np.int32)).max())
+    fl = _floor(20)
     yard = _meta().get("e2e20_ref_fp16", {"pixel_mae": 2.858e-3, "u8_max_diff": 10})
-    G.log_metric(test="stress_e2e20", pixel_mae=mae, u8_max_diff=mx, ref_fp16_mae=yard["pixel_mae"], ref_fp16_u8=yard["u8_max_diff"])
-    assert mae < 0.75 * yard["pixel_mae"] and mx <= 6, f"pixel MAE {mae:.2e} (torch-CPU fp16 reference: {yard['pixel_mae']:.2e}), uint8 max diff {mx}"
+    G.log_metric(test="stress_e2e20", pixel_mae=mae, u8_max_diff=mx, floor=fl, ref_fp16_mae=yard["pixel_mae"], ref_fp16_u8=yard["u8_max_diff"])
+    bound = _floor_bound(fl)
+    assert mae < bound and mx <= 6, f"pixel MAE {mae:.2e} (bound {bound:.2e} = {STRESS_FLOOR_MARGIN} x the fp16-storage floor), uint8 max diff {mx}"
+
+
+def test_stress_e2e_txt2img_50_steps():
+    """the same at BASELINE configs[1]'s own 50 steps (tests/golden/stress_e2e50.npz: uint8 image + the decoder's float image at
+    full resolution); floor from tests/golden/stress_floor50.json"""
+    from pytorch_stable_diffusion_amd import pipeline
+    from pytorch_stable_diffusion_amd.tokenizer import StubTokenizer
+    gold = np.load(os.path.join(H.GOLDEN, "stress_e2e50.npz"))
+    models = _stress_models()
+
+    class Tap:
+        def __init__(self, inner):
+            self.inner, self.last = inner, None
+
+        def to(self, d):
+            self.inner.to(d)
+            return self
+
+        def __call__(self, *a):
+            self.last = self.inner(*a).clone()
+            return self.last
+
+    models["decoder"] = Tap(models["decoder"])
+    img = pipeline.generate(prompt="a dog", uncond_prompt="", input_image=None, strength=0.8, do_cfg=True, cfg_scale=7.5,
+                            sampler_name="ddpm", n_inference_steps=50, models=models, seed=42, device=DEV, idle_device=None,
+                            tokenizer=StubTokenizer())
+    ref = gold["u8"]
+    mae = float(np.abs(img.astype(np.float64) - ref.astype(np.float64)).mean() / 255.0)
+    mx = int(np.abs(img.astype(np.int32) - ref.astype(np.int32)).max())
+    fmae = float((models["decoder"].last[0].cpu().float() - torch.from_numpy(gold["float16"]).float()).abs().mean() / 2.0)   # [-1,1] -> [0,1]
+    fl = _floor(50)
+    G.log_metric(test="stress_e2e50", pixel_mae=mae, float_mae_full_res=fmae, u8_max_diff=mx, floor=fl)
+    bound = _floor_bound(fl)
+    assert mae < bound and fmae < bound and mx <= 8, f"pixel MAE {mae:.2e} / float {fmae:.2e} (bound {bound:.2e}), uint8 max diff {mx}"
 
 
 def test_stress_per_block_attribution(stress_unet):
@@ -336,3 +396,90 @@ def test_stress_per_block_attribution(stress_unet):
     assert len(rows) >= 40
     for r in rows:
         assert r["rel_l2"] < 2.7e-3, f"{r['op']}: rel L2 {r['rel_l2']:.2e}"
+
+
+@pytest.mark.parametrize("mean_sigma,expect", [(0, 0), (3, 0), (10, 1), (30, 1)])
+def test_ln_fold_guard_counts_rows_beyond_the_threshold(mean_sigma, expect):
+    """The guard of the LayerNorm fold (sdmi_gemm_desc::ln_guard, csrc/gemm.hip prologue): a folded GEMM counts the rows whose
+    |mean| exceeds 8 sigma -- each row once, whatever the tiling -- so the caller can repeat its loop through the separate
+    LayerNorm kernel.  Rows of the stress law (<= 3 sigma) never trip it."""
+    M, Cc, Nn = 256, 640, 640
+    g = torch.Generator().manual_seed(17 + mean_sigma)
+    x = _stress_rows(M, Cc, mean_sigma, 0, g)
+    gamma, beta = _stress_norm(Cc, g)
+    w = _stress_weight(Nn, Cc, g)
+    bias = torch.randn((Nn,), generator=g)
+    wf, gf, hf = G.ln_fold_prep(w.to(DEV), gamma.to(DEV), beta.to(DEV), bias.to(DEV))
+    a = torch.zeros((M, Cc)).half()
+    wp = torch.zeros((Cc, Cc)).half()
+    for cfg in (1, 9):                                       # 128x128 and 64x64 tiles: the count does not depend on the tiling
+        bn = G.gemm_tile(cfg)[1]
+        ntn = (Cc + bn - 1) // bn
+        rowstat = torch.full((M, ntn, 2), float("nan"), device=DEV)
+        x32, x16 = G.igemm(a.to(DEV).view(1, M, 1, Cc), wp.to(DEV), B=1, Hs=M, Ws=1, Ho=M, Wo=1, res=x.to(DEV), out_f32=True, cfg=cfg,
+                           want16=True, rowstat=rowstat)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=DEV)
+        G.igemm(x16.view(1, M, 1, Cc), wf, B=1, Hs=M, Ws=1, Ho=M, Wo=1, bias=hf, out_f32=True, ln_stat=rowstat, ln_g=gf, ln_c=Cc, cfg=cfg,
+                ln_guard=cnt)
+        assert int(cnt.item()) == (M if expect else 0), f"cfg {cfg}: {int(cnt.item())} rows counted at {mean_sigma} sigma"
+
+
+def test_ln_fold_guard_fallback_path(stress_handle, monkeypatch):
+    """Handle level: no row of the stress-law blocks trips the guard; with the fold switched off (what the fallback does) the
+    block runs through the separate LayerNorm kernel -- more launches, the same result within the block bounds -- and
+    Diffusion.denoise_native repeats its loop unfused, on the same noise stream, when the counter is not zero."""
+    h = stress_handle
+    m = _meta()["blocks"]["attn_8_80_s16"]
+    ref = torch.from_numpy(H.load_npz("stress.npz")["attn_8_80_s16"])
+    x = H.stress_input(tuple(m["ishape"]), m["seed"])
+    oshape = (ref.shape[0], ref.shape[2], ref.shape[3], ref.shape[1])
+    h.ln_guard(reset=True)
+    y1 = h.run_block(m["prefix"], 1, _nhwc(x).to(DEV), out_shape=oshape).permute(0, 3, 1, 2).cpu()
+    n1 = h.last_launch_count
+    assert h.ln_guard(reset=True) == 0
+    h.ln_guard(fold_on=False)
+    try:
+        y2 = h.run_block(m["prefix"], 1, _nhwc(x).to(DEV), out_shape=oshape).permute(0, 3, 1, 2).cpu()
+        n2 = h.last_launch_count
+    finally:
+        h.ln_guard(fold_on=True)
+    assert n2 > n1, (n1, n2)
+    assert H.rel_l2(y2, ref) < STRESS_BLOCK_REL_L2 and H.rel_l2(y1, ref) < STRESS_BLOCK_REL_L2
+    y3 = h.run_block(m["prefix"], 1, _nhwc(x).to(DEV), out_shape=oshape).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(y1, y3)                                   # switched back: the folded path again, bit for bit
+
+
+def test_denoise_native_repeats_unfused_when_the_guard_fires(monkeypatch):
+    from pytorch_stable_diffusion_amd import arch, synth
+    from pytorch_stable_diffusion_amd.ddpm import DDPMSampler
+    from pytorch_stable_diffusion_amd.diffusion import Diffusion
+    model = Diffusion(stream_f32=True)
+    model.load_state_dict(synth.synth_state_dict(arch.diffusion_manifest()), strict=True)
+    model.to(DEV)
+    try:
+        ctx = H.seeded((2, 77, 768), 1).to(DEV)
+        lat = H.seeded((1, 4, 16, 16), 3).to(DEV)
+
+        def run():
+            smp = DDPMSampler(torch.Generator().manual_seed(5))
+            smp.set_inference_timesteps(4)
+            return model.denoise_native(lat, ctx, smp, smp.timesteps.tolist(), True, 7.5).cpu()
+
+        base = run()
+        assert model.ln_guard_hits == 0
+        h = model.handle()
+        real, calls = h.ln_guard, []
+
+        def fake(reset=True, fold_on=None):
+            calls.append(fold_on)
+            v = real(reset=reset, fold_on=fold_on)
+            return 7 if len(calls) == 2 else v                  # the read after the first loop reports hits
+
+        monkeypatch.setattr(h, "ln_guard", fake)
+        again = run()
+        assert model.ln_guard_hits == 7 and False in calls and calls[-1] is True      # unfused loop ran, the fold is back on
+        assert not torch.equal(again, base) and H.rel_l2(again, base) < 2e-3         # another summation order, the same image
+        monkeypatch.setattr(h, "ln_guard", real)
+        assert torch.equal(run(), base)
+    finally:
+        model._drop_handle()
