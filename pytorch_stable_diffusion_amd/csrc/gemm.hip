@@ -878,14 +878,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   const int nkt = 9 * nchunk;
   const int kt0 = kz * p.ksteps_per;                 // multiple of 9 (launcher)
   const int kt1 = min(kt0 + p.ksteps_per, nkt);
-  // Extra 1x1 segment (the ResBlock's skip conv fused into conv_merged: GemmArgs::x0 / x1): (X0 + X1) / 64 more K-steps behind
-  // the taps, taken by the LAST K-slice.  An extra chunk is staged like a conv chunk -- its 64 channels of the (TH + 2) input
-  // rows into a halo buffer -- and multiplied once, with the centre tap.  "Unified" chunk index: [0, nchunk) conv chunks of
-  // nine K-steps, [nchunk, nchunk + nx) extra chunks of one.
-  const int nx = kt1 == nkt ? (p.X0 + p.X1) >> 6 : 0;
-  const int nk = kt1 - kt0 + nx;
+  const int nk = kt1 - kt0;
   const int c_first = kt0 / 9;
-  const int c_end = kt1 / 9 + nx;                    // unified chunks [c_first, c_end) belong to this K-slice
 
   const int W = p.Wo, Hh = p.Ho, W2 = W + 2;
   const int TH = BM / W;
@@ -925,13 +919,11 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       h_lds[t] = q < NHI ? (hy * W2 + 1 + seg * 8) * 128 : -1;   // wave-uniform LDS byte offset of the piece
     }
     auto halo_piece = [&](int t, int chunk, char* hb) {
-      const bool extra = chunk >= nchunk;             // (unified index: see nx above; the x sources have the output's spatial size)
-      const int cabs = (extra ? chunk - nchunk : chunk) << 6;
-      const int Ca = extra ? p.X0 : p.C0;
-      const bool second = cabs >= Ca;
-      const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
-      const int ld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
-      const int cc = second ? cabs - Ca : cabs;
+      const int cabs = chunk << 6;
+      const bool second = cabs >= p.C0;
+      const f16* base = second ? p.a1 : p.a0;
+      const int ld = second ? p.lda1 : p.lda0;
+      const int cc = second ? cabs - p.C0 : cabs;
       const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
       const f16* gz = p.zero + h_gch[t];
       const f16* g = h_in[t] ? base + ((size_t)h_pix[t] * ld + cc + h_gch[t]) : gz;
@@ -949,21 +941,15 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       b_ok[i] = n < p.N;
       b_ptr[i] = b_ok[i] ? p.w + (size_t)n * p.ldw + (size_t)c_first * 64 + gch : p.zero + gch;
     }
-    int tap = 0, chunk = c_first;                     // the K-step staged next
+    int tap = 0, chunk = c_first;
     auto stage_b = [&](int slot) {
       char* sb = bring + slot * C::B_BYTES;
-      // weight columns of the next K-step: the next tap of this chunk (+ Cin), tap 0 of the next chunk (+ 64 - 8 Cin), or --
-      // behind the last conv chunk and between extra chunks -- the next 64 columns of the extra segment (+ 64: it starts at
-      // 9 Cin = 8 Cin + nchunk * 64)
-      int inc;
-      if (chunk >= nchunk) { inc = 64; ++chunk; }
-      else if (tap < 8) { inc = Cin; ++tap; }
-      else { tap = 0; ++chunk; inc = chunk < nchunk ? 64 - 8 * Cin : 64; }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         glds16(b_ptr[i], sb + (i * NW + wave) * 1024);
-        if (b_ok[i]) b_ptr[i] += inc;
+        if (b_ok[i]) b_ptr[i] += (tap == 8) ? (64 - 8 * Cin) : Cin;
       }
+      if (++tap == 9) { tap = 0; ++chunk; }
     };
     // prologue: whole halo of the first chunk + first NS-1 weight tiles
 #pragma unroll
@@ -982,24 +968,14 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-      const bool have_next = cchunk + 1 < c_end;
-      char* hb_next = ((cchunk + 1 - c_first) & 1) ? hb1 : hb0;
-      const bool extra_now = cchunk >= nchunk;        // an extra chunk is being multiplied: ONE interval, not nine
-      if (extra_now) {
-        // the tail of the last K-slice: the next extra chunk's whole halo in this one interval, and a plain wait for
-        // everything (a handful of intervals per launch: no counted overlap here)
-        if (t + NS - 1 < nk) stage_b(nxt);
-        if (have_next) {
-#pragma unroll
-          for (int tt = 0; tt < NTAPH; ++tt) halo_piece(tt, cchunk + 1, hb_next);
-        }
-      } else if (t + NS - 1 < nk) {
+      if (t + NS - 1 < nk) {
         stage_b(nxt);
         // one halo piece of the NEXT chunk (dummy DMA keeps the per-interval count constant)
+        const bool have_next = (cchunk + 1) * 9 < kt1;
         if (ctap < NTAPH && have_next) {
 #pragma unroll
           for (int tt = 0; tt < NTAPH; ++tt)
-            if (tt == ctap) halo_piece(tt, cchunk + 1, hb_next);
+            if (tt == ctap) halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
         } else {
           glds16(p.zero, dump);
         }
@@ -1008,8 +984,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       const unsigned long long s1 = __builtin_amdgcn_s_memtime();
 #endif
       const int rem = nk - 2 - t;
-      if (extra_now) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+      if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
       else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SDMI_CLK_PROBE_FINE
@@ -1020,8 +995,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += __builtin_amdgcn_s_memtime() - s2;
 #endif
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      if (extra_now) ++cchunk;
-      else if (++ctap == 9) { ctap = 0; ++cchunk; }
+      if (++ctap == 9) { ctap = 0; ++cchunk; }
     }
 #ifdef SDMI_CLK_PROBE_FINE
     if (lane == 0 && wave == 0 && blockIdx.x < 512) {
@@ -1062,8 +1036,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
-      const bool extra_now = c_first + cchunk >= nchunk;       // an extra chunk: the centre tap, one K-step
-      const int kh = extra_now ? 1 : ctap / 3, kw = extra_now ? 1 : ctap - (ctap / 3) * 3;
+      const int kh = ctap / 3, kw = ctap - kh * 3;
       const char* hb = (cchunk & 1) ? hb1 : hb0;
       const char* Bs = bring + cur * C::B_BYTES + b_row_off;
       int a_off[FM], a_co[FM];
@@ -1102,8 +1075,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       acc_cmp += s1 - s0; acc_cbar += __builtin_amdgcn_s_memtime() - s1;
 #endif
       cur = (cur + 1 == NS) ? 0 : cur + 1;
-      if (extra_now) ++cchunk;
-      else if (++ctap == 9) { ctap = 0; ++cchunk; }
+      if (++ctap == 9) { ctap = 0; ++cchunk; }
     }
 #ifdef SDMI_CLK_PROBE_FINE
     if (lane == 0 && wave == 0 && blockIdx.x < 512) {
@@ -1252,17 +1224,17 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   }
 }
 
-// The same combine with the GroupNorm statistics of the result (GnRec, common.h) taken on the way: a workgroup of 320 threads
+// The same combine with the GroupNorm statistics of the result (GnRec, common.h) taken on the way: a workgroup of 640 threads
 // takes `rows_wg` consecutive rows of one image and one 320-column slice of them, thread t always column chunk t % 40, so the
-// moments of its 8 columns stay in four registers; one record per thread in LDS, then one thread per atom of the slice adds
+// moments of its 8 columns stay in registers; one record per thread in LDS, then one thread per atom of the slice adds
 // its chunks' records in a fixed order (fp64) and stores them as this row block's record.
-constexpr int kFinNT = 320, kFinCols = 320;
-template <int NI>          // rows per workgroup = 8 NI: the NI items of a thread are unrolled, so their slab loads fly together
+constexpr int kFinNT = 640, kFinCols = 320;     // 40 column chunks x 16 rows per pass (320 threads and twice the items per thread: 1 - 2 us slower per launch)
+template <int NI>          // rows per workgroup = 16 NI: the NI items of a thread are unrolled, so their slab loads fly together
 __global__ __launch_bounds__(kFinNT) void splitk_finalize_gacc_kernel(GemmArgs p, int nsl) {
   sdmi_kernarg_warm<sizeof(GemmArgs) + 8>();
   __shared__ float s_g[kFinNT * 4];
   const int tid = threadIdx.x;
-  constexpr int n8 = kFinCols / 8, rpp = kFinNT / n8;   // 40 column chunks, 8 rows per pass
+  constexpr int n8 = kFinCols / 8, rpp = kFinNT / n8;   // 40 column chunks, 16 rows per pass
   constexpr int rows_wg = NI * rpp;
   const int rb = blockIdx.x / nsl, cs = blockIdx.x - rb * nsl;
   const int c8 = tid % n8, r0 = tid / n8;
@@ -1398,8 +1370,7 @@ void sdmi_gemm_cfg_dims(int cfg, int* bm, int* bn) {
 
 // halo-reuse kernel applicability: 3x3 stride-1 pad-1, tile = whole image rows inside one image
 static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
-  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.rowstat || a.ln_stat) return false;
-  if ((a.X0 || a.X1) && (a.ups != 0 || a.X0 % 64 != 0 || a.X1 % 64 != 0 || !a.x0)) return false;    // extra 1x1 segment: sources on the output grid
+  if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.X0 != 0 || a.rowstat || a.ln_stat) return false;
   if ((a.Hs << a.ups) != a.Ho || (a.Ws << a.ups) != a.Wo) return false;
   if (a.Wo % 8 != 0 || c.BM % a.Wo != 0 || (a.Ho * a.Wo) % c.BM != 0 || a.M % c.BM != 0) return false;
   const int TH = c.BM / a.Wo;
@@ -1512,16 +1483,9 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     const double a_bytes = 2.0 * ((double)a.M * a.stride * a.stride / (a.ups ? 4 : 1)) * (a.C0 + a.C1) + 2.0 * a.M * (a.X0 + a.X1);
     p.n_major = force >= 0 ? force : (w_bytes > a_bytes);
   }
-  if (halo) {
-    // the halo kernel splits the CONV K-steps at channel-chunk boundaries (9 taps each); the extra 1x1 segment rides with the last slice
-    const int nkc = 9 * ((a.C0 + a.C1) / 64);
-    if (p.ksplit > nkc / 9) p.ksplit = nkc / 9;
-    p.ksteps_per = ((nkc + p.ksplit - 1) / p.ksplit + 8) / 9 * 9;
-    p.ksplit = (nkc + p.ksteps_per - 1) / p.ksteps_per;
-  } else {
-    p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
-    p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
-  }
+  p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
+  if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
+  p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
   const int tiles_m = (a.M + c.BM - 1) / c.BM, tiles_n = (a.N + c.BN - 1) / c.BN;
   const int tiles = tiles_m * tiles_n;
@@ -1564,22 +1528,22 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   return SDMI_OK;
 }
 
-// rows per workgroup of the statistics-taking combine (0: this shape cannot take it): a multiple of the 8 rows per pass that
+// rows per workgroup of the statistics-taking combine (0: this shape cannot take it): a multiple of the 16 rows per pass that
 // divides the rows of an image, few enough record rows, aiming at >= 256 workgroups
 static int finalize_gacc_rows(const GemmArgs& a) {
   if (!a.gacc.rec || a.outT || a.N % kFinCols != 0 || !gacc_atom_ok(a.gacc.atom) || kFinCols % a.gacc.atom != 0 ||
       a.gacc.natoms * a.gacc.atom != a.N || a.gacc.rows_img <= 0 || a.gacc.mod % a.gacc.rows_img != 0 || a.M % a.gacc.mod != 0)
     return 0;
   const int nsl = a.N / kFinCols, phases = a.M / a.gacc.mod;
-  int rows = 8;
+  int rows = kFinNT / (kFinCols / 8);
   if (a.gacc.rows_img % rows != 0) return 0;
   auto recs = [&](int r) { return (long)phases * (a.gacc.rows_img / r) * a.gacc.natoms; };
   while (recs(rows) > kGaccMaxRec) {
     if (a.gacc.rows_img % (rows * 2) != 0) return 0;
     rows *= 2;
   }
-  while (rows < 64 && a.gacc.rows_img % (rows * 2) == 0 && (long)(a.M / (rows * 2)) * nsl >= 256) rows *= 2;
-  return rows <= 64 ? rows : 0;           // (8 items per thread at most: kernel instantiations below)
+  while (rows < 128 && a.gacc.rows_img % (rows * 2) == 0 && (long)(a.M / (rows * 2)) * nsl >= 256) rows *= 2;
+  return rows <= 128 ? rows : 0;          // (8 items per thread at most: kernel instantiations below)
 }
 bool sdmi_finalize_gacc_ok(const GemmArgs& a, int* T_out) {
   const int rows = finalize_gacc_rows(a);
@@ -1598,7 +1562,7 @@ int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st) {
     SDMI_REQUIRE(a.gacc.parts == 1 && a.gacc.T == (a.M / a.gacc.mod) * (a.gacc.rows_img / rows), "splitk_finalize: statistics record rows T=%d parts=%d do not match the launch", a.gacc.T, a.gacc.parts);
     const int nsl = a.N / kFinCols;
     const dim3 grid((a.M / rows) * nsl), block(kFinNT);
-    switch (rows / 8) {
+    switch (rows / (kFinNT / (kFinCols / 8))) {
       case 1: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<1>, grid, block, 0, st, a, nsl); break;
       case 2: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<2>, grid, block, 0, st, a, nsl); break;
       case 4: hipLaunchKernelGGL(splitk_finalize_gacc_kernel<4>, grid, block, 0, st, a, nsl); break;

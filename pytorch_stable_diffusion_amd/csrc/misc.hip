@@ -79,45 +79,70 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const
 
 // Stem conv 4 -> Cout, 3x3 s1 p1 (sd/diffusion.py:545), input NCHW fp32 latents (batch-broadcast
 // implements latents.repeat(2,1,1,1) of sd/pipeline.py:221 without a copy), output NHWC.
-// w36: [36][Cout] fp32 with k = (kh*3+kw)*4 + ci.   thread = (pixel, 8 output channels)
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* lat, int lat_batch, const float* w36,
-                                                        const float* bias, void* out, int out_f32, f16* out16,
-                                                        int B, int H, int W, int Cout, int Cin) {
+// w36: [36][Cout] fp32 with k = (kh*3+kw)*4 + ci.
+// A lane is a pixel, a wave takes `cpw` chunks of 8 output channels for its 64 pixels: the pixel's 3x3 x Cin neighbourhood
+// is loaded once (<= 36 loads in flight, zeros outside the map) and the weights are wave-uniform, so they come through
+// the scalar cache (s_load_dwordx8) instead of 36 x 32 B per thread through the texture path -- the form with a thread per
+// (pixel, chunk) spent 18 us a step on exactly that traffic.  Products are added in (kh, kw, ci) order onto the bias, as before.
+template <int CIN>
+__global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restrict__ lat, int lat_batch, const float* __restrict__ w36,
+                                                        const float* __restrict__ bias, void* out, int out_f32, f16* out16,
+                                                        int B, int H, int W, int Cout, int cpw, int nchunk) {
+  constexpr int Cin = CIN;
+  const int lane = threadIdx.x & 63;
+  const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  const unsigned grp = gw / (unsigned)nchunk;
+  const int chunk = (int)(gw - grp * nchunk);
+  const unsigned npix = (unsigned)B * H * W;                           // < 2^31: 32-bit index math
+  const unsigned pix = grp * 64u + lane;
+  if (grp * 64u >= npix) return;
+  const bool live = pix < npix;
+  const unsigned pc = live ? pix : npix - 1;
+  const unsigned prow = pc / (unsigned)W;
+  const int ow = (int)(pc - prow * W);
+  const int b = (int)(prow / (unsigned)H);
+  const int oh = (int)(prow - (unsigned)b * H);
+  const int lb = b % lat_batch;                 // latents.repeat(batch / lat_batch, 1, 1, 1): image b reads latent b mod lat_batch
+  f32x2 xv[9][CIN];                              // (x, x): the packed FMA's multiplicand, made once per value
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+    const bool in = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float v = lat[(((unsigned)lb * Cin + ci) * H + (in ? ih : 0)) * W + (in ? iw : 0)];   // always a valid address
+      xv[t][ci] = in ? f32x2{v, v} : f32x2{0.f, 0.f};
+      asm volatile("" : "+v"(xv[t][ci]));      // one register pair per value (the compiler otherwise keeps a copy per use and spills)
+    }
+  }
   const int C8 = Cout / 8;
-  const unsigned total = (unsigned)B * H * W * C8;                     // < 2^31: 32-bit index math
-  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-    const unsigned pix = idx / (unsigned)C8;
-    const int c8 = (int)(idx - pix * C8);
-    const unsigned prow = pix / (unsigned)W;
-    const int ow = (int)(pix - prow * W);
-    const int b = (int)(prow / (unsigned)H);
-    const int oh = (int)(prow - (unsigned)b * H);
-    const int lb = b % lat_batch;                 // latents.repeat(batch / lat_batch, 1, 1, 1): image b reads latent b mod lat_batch
+  const int c_end = min(C8, (chunk + 1) * cpw);
+  for (int c8 = chunk * cpw; c8 < c_end; ++c8) {
+    f32x2 a2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a2[j] = *(const f32x2*)(bias + c8 * 8 + 2 * j);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+          const f32x2* wp = (const f32x2*)(w36 + (unsigned)((t * Cin + ci) * Cout + c8 * 8));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a2[j] = __builtin_elementwise_fma(xv[t][ci], wp[j], a2[j]);
+        }
+      __builtin_amdgcn_sched_barrier(0);       // one tap's 32 weight SGPRs at a time (all 288 hoisted would spill into VGPRs)
+    }
     float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias[c8 * 8 + e];
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ih = oh + kh - 1;
-      if ((unsigned)ih >= (unsigned)H) continue;
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow + kw - 1;
-        if ((unsigned)iw >= (unsigned)W) continue;
-        for (int ci = 0; ci < Cin; ++ci) {
-          const float xv = lat[(((size_t)lb * Cin + ci) * H + ih) * W + iw];
-          const float* wp = w36 + (size_t)((kh * 3 + kw) * Cin + ci) * Cout + c8 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] += xv * wp[e];
-        }
-      }
-    }
+    for (int j = 0; j < 4; ++j) { acc[2 * j] = a2[j][0]; acc[2 * j + 1] = a2[j][1]; }
+    if (!live) continue;
     f16x8 o16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o16[e] = (f16)acc[e];
     const size_t off = (size_t)pix * Cout + c8 * 8;
     if (out_f32) {
       float* op = (float*)out + off;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) op[e] = acc[e];
+      *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *(f32x4*)(op + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
       if (out16) *(f16x8*)(out16 + off) = o16;
     } else {
       *(f16x8*)((f16*)out + off) = o16;
@@ -136,44 +161,65 @@ __global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout,
 }
 
 // Output conv Cin -> 4, 3x3 s1 p1 (sd/diffusion.py:744) on the GN+SiLU'd NHWC fp16 tensor,
-// result NCHW fp32 (B,4,H,W).  One wave per output pixel; w packed [4][3][3][Cin] fp16.
+// result NCHW fp32 (B,4,H,W).  One wave per FOUR consecutive output pixels of a row (round 4: one per pixel re-read the
+// 23 KB of weights for every pixel -- 190 MB per step out of L1/L2, 16 us): a lane takes (tap, 8-channel chunk) items, loads
+// the item's weights once and multiplies them with the four pixels' inputs; w packed [4][3][3][Cin] fp16.
+constexpr int FC_PX = 4;
+template <int NCO>        // output channels the kernel holds accumulators for: 4 (UNet eps, VAE image) or 8 (VAE encoder moments)
 __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16* w, const float* bias, float* out,
                                                          int B, int H, int W, int Cin, int Cout) {
   const int lane = threadIdx.x & 63;
-  const unsigned pix = blockIdx.x * 4u + (threadIdx.x >> 6);          // < 2^31 pixels: 32-bit index math
-  const unsigned npix = (unsigned)B * H * W;
-  if (pix >= npix) return;
-  const unsigned prow = pix / (unsigned)W;
-  const int ow = (int)(pix - prow * W);
+  const unsigned grp = blockIdx.x * 4u + (threadIdx.x >> 6);          // group of FC_PX pixels (W % FC_PX == 0: launcher)
+  const unsigned ngrp = (unsigned)B * H * W / FC_PX;
+  if (grp >= ngrp) return;
+  const unsigned pix0 = grp * FC_PX;
+  const unsigned prow = pix0 / (unsigned)W;
+  const int ow0 = (int)(pix0 - prow * W);
   const int b = (int)(prow / (unsigned)H);
   const int oh = (int)(prow - (unsigned)b * H);
   const int C8 = Cin / 8;
   const int items = 9 * C8;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float acc[FC_PX][NCO];
+#pragma unroll
+  for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[px][co] = 0.f;
   for (int it = lane; it < items; it += 64) {
     const int tap = it / C8, c8 = it - tap * C8;
     const int kh = tap / 3, kw = tap - kh * 3;
-    const int ih = oh + kh - 1, iw = ow + kw - 1;
-    if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
-    const f16x8 xv = *(const f16x8*)(x + (((size_t)b * H + ih) * W + iw) * Cin + c8 * 8);
+    const int ih = oh + kh - 1;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    f16x8 wv[NCO];
 #pragma unroll
-    for (int co = 0; co < 8; ++co) {
-      if (co < Cout) {
-        const f16x8 wv = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
+    for (int co = 0; co < NCO; ++co) wv[co] = co < Cout ? *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8) : f16x8{};
+    f16x8 xv[FC_PX];
+#pragma unroll
+    for (int px = 0; px < FC_PX; ++px) {
+      const int iw = ow0 + px + kw - 1;
+      xv[px] = (unsigned)iw < (unsigned)W ? *(const f16x8*)(x + (((size_t)b * H + ih) * W + iw) * Cin + c8 * 8) : f16x8{};
+    }
+#pragma unroll
+    for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
 #pragma unroll
         for (int e = 0; e < 8; e += 2)      // v_dot2_f32_f16: two fp16 products + fp32 accumulate per instruction
-          acc[co] = __builtin_amdgcn_fdot2(f16x2{xv[e], xv[e + 1]}, f16x2{wv[e], wv[e + 1]}, acc[co], false);
-      }
-    }
+          acc[px][co] = __builtin_amdgcn_fdot2(f16x2{xv[px][e], xv[px][e + 1]}, f16x2{wv[co][e], wv[co][e + 1]}, acc[px][co], false);
   }
 #pragma unroll
-  for (int co = 0; co < 8; ++co)
+  for (int px = 0; px < FC_PX; ++px)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o);
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[px][co] += __shfl_xor(acc[px][co], o);
   if (lane == 0) {
 #pragma unroll
-    for (int co = 0; co < 8; ++co)
-      if (co < Cout) out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + bias[co];
+    for (int co = 0; co < NCO; ++co)
+      if (co < Cout) {
+        float* op = out + (((size_t)b * Cout + co) * H + oh) * W + ow0;
+#pragma unroll
+        for (int px = 0; px < FC_PX; ++px) op[px] = acc[px][co] + bias[co];
+      }
   }
 }
 
@@ -507,20 +553,35 @@ int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float
 int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias, void* out,
                           int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st) {
   SDMI_REQUIRE(Cout % 8 == 0 && Cin >= 1 && Cin <= 4, "stem conv: Cout=%d Cin=%d", Cout, Cin);
-  const size_t total = (size_t)B * H * W * (Cout / 8);
-  SDMI_REQUIRE(total < ((size_t)1 << 31), "stem conv: too many outputs");
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(nblocks(total)), dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32,
-                     out16, B, H, W, Cout, Cin);
+  const size_t npix = (size_t)B * H * W;
+  SDMI_REQUIRE(npix * Cout < ((size_t)1 << 31), "stem conv: too many outputs");
+  const int C8 = Cout / 8;
+  const size_t groups = (npix + 63) / 64;
+  // chunks of 8 channels per wave: as many as keeps >= ~2048 waves in the launch (the neighbourhood loads are per wave)
+  const int cpw = (int)std::max<size_t>(1, std::min<size_t>((size_t)C8, (size_t)C8 * groups / 2048));
+  const int nchunk = (C8 + cpw - 1) / cpw;
+  const size_t waves = groups * nchunk;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+#define SDMI_STEM(CI) hipLaunchKernelGGL(stem_conv_kernel<CI>, grid, dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32, out16, B, H, W, Cout, cpw, nchunk)
+  switch (Cin) {
+    case 1: SDMI_STEM(1); break;
+    case 2: SDMI_STEM(2); break;
+    case 3: SDMI_STEM(3); break;
+    default: SDMI_STEM(4); break;
+  }
+#undef SDMI_STEM
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
 
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W, int Cin,
                            int Cout, hipStream_t st) {
-  SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "final conv: Cin=%d Cout=%d", Cin, Cout);
+  SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 8 && W % FC_PX == 0, "final conv: Cin=%d Cout=%d W=%d (Cout <= 8, W a multiple of %d)", Cin, Cout, W, FC_PX);
   const size_t npix = (size_t)B * H * W;
   SDMI_REQUIRE(npix < ((size_t)1 << 31), "final conv: too many pixels");
-  hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
+  const size_t ngrp = npix / FC_PX;
+  if (Cout <= 4) hipLaunchKernelGGL(final_conv_kernel<4>, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
+  else hipLaunchKernelGGL(final_conv_kernel<8>, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -31,6 +31,7 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference/sd")
 
 from pytorch_stable_diffusion_amd import model_loader  # noqa: E402
+from tests import helpers as H  # noqa: E402
 from tests.stub_tokenizer import StubTokenizer  # noqa: E402
 
 OUT = os.path.join(HERE, "e2e50.npz")
@@ -60,6 +61,8 @@ def record(out, tag, img, dec, unet):
     lat_in = torch.cat(unet.inputs)                     # (n_steps, 4, h, w): latents entering each UNet call
     out[f"{tag}_u8"] = img
     out[f"{tag}_float"] = dec.last[0, :, ::4, ::4].numpy()
+    if tag == "txt50":
+        out[f"{tag}_float_u16"] = H.float_image_u16(dec.last[0])      # FULL resolution, [-1,1] clamped, 16-bit fixed point
     out[f"{tag}_latents"] = dec.last_in.numpy()         # Tap clones before the decoder's in-place /0.18215
     out[f"{tag}_lat_every5"] = lat_in[::5].numpy()
     out[f"{tag}_lat_stats"] = torch.stack([lat_in.mean(dim=(1, 2, 3)), lat_in.std(dim=(1, 2, 3))], 1).numpy()

@@ -114,8 +114,9 @@ class Tap(torch.nn.Module):
         self.last_in = a[0].clone()
         if self.keep:
             self.inputs.append(a[0][:1].clone())
-        self.last = self.inner(*a).clone()
-        return self.last
+        out = self.inner(*a)
+        self.last = out.clone()            # the caller rescales ``out`` in place (sd/pipeline.py:246)
+        return out
 
 
 @torch.no_grad()
@@ -143,8 +144,8 @@ def e2e(unet_mod, steps=20):
     lat_in = torch.cat(unet.inputs)
     if steps != 20:
         # BASELINE configs[1]'s own step count under the stress law: the uint8 image, the decoder's float image at FULL
-        # resolution (fp16: 1.5 MB) and the latents entering every 5th step
-        np.savez_compressed(os.path.join(HERE, f"stress_e2e{steps}.npz"), u8=img, float16=dect.last[0].half().numpy(),
+        # resolution ([-1,1] clamped, 16-bit fixed point: 1.5e-5 of the range per count) and the latents entering every 5th step
+        np.savez_compressed(os.path.join(HERE, f"stress_e2e{steps}.npz"), u8=img, float_u16=H.float_image_u16(dect.last[0]),
                             latents=dect.last_in.numpy(), lat_every5=lat_in[::5].numpy(), threads=np.array(torch.get_num_threads()))
         return
     np.savez_compressed(os.path.join(HERE, "stress_e2e.npz"),

@@ -78,3 +78,18 @@ def inverse_checkpoint(state_dicts, plan):
                 assert k not in ckpt, k
                 ckpt[k] = p.contiguous()
     return ckpt
+
+
+def float_image_u16(x):
+    """Decoder output (float, nominally [-1,1]) -> 16-bit fixed point of the clamped image: what the uint8 cast sees, at
+    1.5e-5 of the range per count.  Full-resolution float goldens are stored this way (1.5 MB per 512x512 image)."""
+    import numpy as np
+    y = (x.detach().float().cpu().clamp(-1, 1) + 1) * 0.5 * 65535.0
+    return y.round().numpy().astype(np.uint16)
+
+
+def float_image_mae(x, ref_u16):
+    """Mean |x - ref| on the [0,1] scale, x a float image in [-1,1] (clamped like the reference's rescale), ref from float_image_u16."""
+    import numpy as np
+    y = (x.detach().float().cpu().clamp(-1, 1) + 1) * 0.5
+    return float((y.double() - torch.from_numpy(ref_u16.astype(np.float64) / 65535.0)).abs().mean())

@@ -27,6 +27,9 @@ class FakeTensor:
     def contiguous(self):
         return self
 
+    def is_contiguous(self):
+        return True
+
     def data_ptr(self):
         return 0x1000
 
@@ -74,10 +77,13 @@ def test_every_unet_entry_point_runs_on_the_handles_device(guarded):
     h.set_schedule(FakeTensor((50, 320), d1))
     h.forward(FakeTensor((1, 4, 64, 64), d1), 2, step_idx=0)
     h.denoise_step(FakeTensor((1, 4, 64, 64), d1), 0, True, 7.5, FakeTensor((1, 4, 64, 64), d1), (1, 1, 1, 1, 1))
+    h.denoise_step(FakeTensor((4, 4, 64, 64), d1), 0, True, 7.5, FakeTensor((4, 4, 64, 64), d1), (1, 1, 1, 1, 1))   # 4 prompts, one chain
+    h.ln_guard()
     h.run_block("unet.encoders.1.0", 0, FakeTensor((2, 8, 8, 320), d1), time=FakeTensor((1, 1280), d1), out_shape=(2, 8, 8, 320))
     calls = [e for e in log if e[0] == "call"]
     assert [c[1] for c in calls] == ["sdmi_unet_set_context", "sdmi_unet_set_schedule", "sdmi_unet_forward",
-                                     "sdmi_unet_denoise_step", "sdmi_unet_run_block"]
+                                     "sdmi_unet_denoise_step_batch", "sdmi_unet_denoise_step_batch", "sdmi_unet_ln_guard",
+                                     "sdmi_unet_run_block"]
     assert all(c[2] == torch.device("cuda", 1) for c in calls), calls          # issued while cuda:1 was current
     assert all(e[1] == torch.device("cuda", 1) for e in log if e[0] == "stream")   # on cuda:1's stream
     assert state["current"] == torch.device("cuda", 0)                         # and the caller's device is restored

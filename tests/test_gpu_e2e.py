@@ -52,6 +52,10 @@ def _check(name, img, float_img, g, drift=None):
     G.log_metric(test="e2e", name=name, pixel_mae=mae, u8_max=int(du8.max()), u8_mean=float(du8.mean()), drift=drift)
     assert mae < PIXEL_MAE, f"{name}: pixel MAE {mae:.2e} (latent drift every 5th step: {drift})"
     assert du8.max() <= U8_MAX, f"{name}: uint8 max diff {du8.max()}"
+    if f"{name}_float_u16" in g:           # FULL-resolution float image (16-bit fixed point of the clamped decoder output)
+        full = H.float_image_mae(float_img[0], g[f"{name}_float_u16"])
+        G.log_metric(test="e2e", name=name, pixel_mae_full_res=full)
+        assert full < PIXEL_MAE, f"{name}: full-resolution pixel MAE {full:.2e}"
 
 
 class StepTap:

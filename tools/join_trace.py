@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Join rocprofv3 output with the engine's launch log (SDMI_LAUNCH_LOG): which SHAPE each kernel of a denoising step ran.
 
-  kernel trace  : join_trace.py time <kernel_trace.csv> <launch_log.txt> [step]
-                  -> per shape: launches, us, TF/s, weight GB/s
+  kernel trace  : join_trace.py time <kernel_trace.csv> <launch_log.txt> [step] [--json step_families.json]
+                  -> per shape: launches, us, TF/s, weight GB/s (and the family sums as JSON: what bench.py quotes as roofline.rocprofv3)
   PMC passes    : join_trace.py pmc <fetch counter_collection.csv> <write counter_collection.csv> <launch_log.txt> <out.json>
                   -> per shape: FETCH (x2, gfx950 correction, MI355X_MICROARCH.md) + WRITE bytes per step vs the
                      algorithmic bytes (weights once + activations in/out once)
-  MFMA busy     : join_trace.py mfma <counter_collection.csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> <launch_log.txt> <out.json>
+  MFMA busy     : join_trace.py mfma <counter_collection.csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> <launch_log.txt> <out.json> [step_families.json]
+                  (with the families file: the busy cycles also over the family's kernel time of the TRACE pass x 2.4 GHz)
 
 A step = the kernels from stem_conv to cfg_ddpm; log line i is matched to the i-th kernel of the step whose name fits the
 line's kind (fill kernels of hipMemsetAsync and anything else unknown are skipped)."""
@@ -93,7 +94,7 @@ def family_of(kind):
     return "other"
 
 
-def cmd_time(trace, logp, which=None):
+def cmd_time(trace, logp, which=None, json_out=None):
     rows = read_rows(trace)
     steps = steps_of(rows)
     log = read_log(logp)
@@ -116,6 +117,13 @@ def cmd_time(trace, logp, which=None):
         f[2] += float(kv.get("flops", 0))
     for f, (n, us, fl) in fams.items():
         print(f"  family {f:9s} x{n:3d} {us:8.1f} us" + (f"  {fl / us * 1e-6:7.1f} TF/s" if fl else ""))
+    if json_out:
+        j = {"note": "one denoising step of bench.py under rocprofv3 --kernel-trace, kernels joined with the engine's launch log "
+                     "(tools/join_trace.py time); ms = sum of the family's kernel durations, tflops = executed FLOPs / that",
+             "kernels_per_step": len(step), "step_kernel_ms": round(tot / 1e3, 4)}
+        for f, (n, us, fl) in fams.items():
+            j[f] = {"launches": n, "ms": round(us / 1e3, 4), "tflops": round(fl / us * 1e-6, 2) if fl else None}
+        json.dump(j, open(json_out, "w"), indent=1)
     for k, (n, us, fl, wb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         extra = f"  {fl / us * 1e-6:7.1f} TF/s  {wb / us * 1e-3:7.1f} GB/s weights" if fl else ""
         print(f"  {k:78s} x{n:3d} {us:8.1f} us  avg {us / n:7.2f}{extra}")
@@ -166,8 +174,9 @@ def cmd_pmc(fetch_csv, write_csv, logp, outp):
         print(f"  {k:78s} x{e['launches_per_step']:5.1f} fetch {e['FETCH_SIZE']/1e6:8.1f} MB write {e['WRITE_SIZE']/1e6:7.1f} MB  algorithmic {e['algorithmic']/1e6:7.1f} MB")
 
 
-def cmd_mfma(csv_path, logp, outp):
+def cmd_mfma(csv_path, logp, outp, fam_json=None):
     log = read_log(logp)
+    fam_ms = json.load(open(fam_json)) if fam_json else {}
     allrows = list(csv.DictReader(open(csv_path)))
     by_counter = collections.defaultdict(list)
     for r in allrows:
@@ -192,6 +201,12 @@ def cmd_mfma(csv_path, logp, outp):
             d["mfma_busy_over_sq_busy"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / d["SQ_BUSY_CYCLES"]
         if d.get("GRBM_GUI_ACTIVE"):
             d["mfma_busy_frac_of_chip"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            d["clock_basis"] = ("GRBM_GUI_ACTIVE of THIS counter pass (rocprofv3 serialises the kernels under --pmc): busy cycles of the "
+                                "profiled pass, not wall-clock cycles of the un-profiled step")
+        if isinstance(fam_ms.get(fam), dict) and d.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            wall_cycles = fam_ms[fam]["ms"] * 1e-3 * 2.4e9
+            d["mfma_busy_frac_of_family_wall_time"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (wall_cycles * 1024.0), 4)
+            d["wall_time_basis"] = f"{fam_ms[fam]['ms']} ms of kernel time in the kernel-trace pass x 2.4 GHz nominal x 1024 SIMDs"
         out["families"][fam] = d
     json.dump(out, open(outp, "w"), indent=1)
     print(json.dumps(out["families"], indent=1))
@@ -200,10 +215,16 @@ def cmd_mfma(csv_path, logp, outp):
 if __name__ == "__main__":
     c = sys.argv[1]
     if c == "time":
-        cmd_time(*sys.argv[2:5])
+        rest = sys.argv[2:]
+        jout = None
+        if "--json" in rest:
+            i = rest.index("--json")
+            jout = rest[i + 1]
+            del rest[i:i + 2]
+        cmd_time(*rest[:3], json_out=jout)
     elif c == "pmc":
         cmd_pmc(*sys.argv[2:6])
     elif c == "mfma":
-        cmd_mfma(*sys.argv[2:5])
+        cmd_mfma(*sys.argv[2:6])
     else:
         raise SystemExit(__doc__)

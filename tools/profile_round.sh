@@ -1,9 +1,9 @@
 #!/bin/bash
-# One-call profiling recipe of a round on the GPU box (run through gpurun from the repo root):  tools/profile_round.sh r03
+# One-call profiling recipe of a round on the GPU box (run through gpurun from the repo root):  tools/profile_round.sh r04
 #   kernel trace + launch log -> per-shape times; separate --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy | MFMA ops)
 # Counter passes carry only --kernel-trace besides --pmc (gpurun refuses other trace domains with counters).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -15,9 +15,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/mfma -o m -- $B > /dev/null 2> $out/mfma.err
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/mops -o o -- $B > /dev/null 2> $out/mops.err
 find $out -name "*.csv" | head -20
-python3 tools/join_trace.py time $(find $out/trace -name "*kernel_trace.csv") $out/launch_log.txt > $out/step_by_shape.txt
+python3 tools/join_trace.py time $(find $out/trace -name "*kernel_trace.csv") $out/launch_log.txt --json $out/step_families.json > $out/step_by_shape.txt
 python3 tools/join_trace.py pmc $(find $out/fetch -name "*counter_collection.csv") $(find $out/write -name "*counter_collection.csv") $out/launch_log.txt $out/hbm_traffic_by_shape.json > $out/pmc_summary.txt
-python3 tools/join_trace.py mfma $(find $out/mfma -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_busy.json > $out/mfma_summary.txt
+python3 tools/join_trace.py mfma $(find $out/mfma -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_busy.json $out/step_families.json > $out/mfma_summary.txt
 python3 tools/join_trace.py mfma $(find $out/mops -name "*counter_collection.csv") $out/launch_log.txt $out/mfma_ops.json > $out/mops_summary.txt
 cp $(find $out/trace -name "*kernel_stats.csv") $out/kernel_stats.csv
 python3 - "$out" <<'PY'
@@ -35,4 +35,14 @@ print("launches/step", n)
 PY
 # the raw CSVs are large: keep only the summaries (the merge back is capped at 64 MiB)
 rm -rf $out/trace $out/fetch $out/write $out/mfma $out/mops
+# what the round commits: gpurun_out/<tag>/p/<tag>_* -> copy to profiles/ after the call
+mkdir -p $out/p
+cp $out/step_by_shape.txt $out/p/${tag}_step_by_shape.txt
+cp $out/step_families.json $out/p/${tag}_step_families.json
+cp $out/kernel_stats.csv $out/p/${tag}_rocprofv3_kernel_stats.csv
+cp $out/hbm_traffic_by_shape.json $out/p/${tag}_hbm_traffic_by_shape.json
+cp $out/mfma_busy.json $out/p/${tag}_mfma_busy.json
+cp $out/mfma_ops.json $out/p/${tag}_mfma_ops.json
+cp $out/launch_log.txt $out/p/${tag}_launch_log.txt
+cp $out/bench_trace.json $out/p/${tag}_bench_under_trace.json
 ls -la $out
