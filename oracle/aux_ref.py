@@ -18,9 +18,46 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
-from pytorch_stable_diffusion_amd import arch
 
 SD = Dict[str, torch.Tensor]
+
+# The oracle's OWN statement of the two nn.Sequential bodies and of CLIP's sizes (it shares no wiring with the product:
+# pytorch_stable_diffusion_amd/arch.py has its own tables; tests/test_oracle_golden.py compares the two).
+#   c<k>[s2]:<cin>><cout>  Conv2d k x k (pad 1 for k = 3, 0 for k = 1; "s2": stride 2, pad 0 + the forward's asymmetric pad)
+#   r<cin>><cout>          VAE_ResidualBlock       a<c>  VAE_AttentionBlock       up  nn.Upsample(2)       gn<c>  GroupNorm(32, c)
+ENCODER_STAGES = (               # sd/encoder.py:56-92
+    "c3:3>128 r128>128 r128>128 "
+    "c3s2:128>128 r128>256 r256>256 "
+    "c3s2:256>256 r256>512 r512>512 "
+    "c3s2:512>512 r512>512 r512>512 r512>512 "
+    "a512 r512>512 gn512 silu c3:512>8 c1:8>8").split()
+DECODER_STAGES = (               # sd/decoder.py:235-339
+    "c1:4>4 c3:4>512 r512>512 a512 r512>512 r512>512 r512>512 r512>512 "
+    "up c3:512>512 r512>512 r512>512 r512>512 "
+    "up c3:512>512 r512>256 r256>256 r256>256 "
+    "up c3:256>256 r256>128 r128>128 r128>128 "
+    "gn128 silu c3:128>3").split()
+CLIP_LAYERS, CLIP_HEADS = 12, 12   # sd/clip.py:198-225
+
+
+def parse_stage(tok: str):
+    """'c3s2:128>128' -> ('conv', 128, 128, 3, 2, 0); 'r128>256' -> ('res', 128, 256); 'a512' -> ('attn', 512); ..."""
+    if tok in ("up", "silu"):
+        return (tok,)
+    if tok[0] == "c":
+        head, io = tok.split(":")
+        ks = int(head[1])
+        stride = 2 if head.endswith("s2") else 1
+        cin, cout = (int(v) for v in io.split(">"))
+        return ("conv", cin, cout, ks, stride, 0 if (stride == 2 or ks == 1) else 1)
+    if tok[0] == "r":
+        cin, cout = (int(v) for v in tok[1:].split(">"))
+        return ("res", cin, cout)
+    if tok[0] == "a":
+        return ("attn", int(tok[1:]))
+    if tok.startswith("gn"):
+        return ("gn", int(tok[2:]))
+    raise ValueError(tok)
 
 
 def _res(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
@@ -46,8 +83,9 @@ def _attn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 
 def _run(sd: SD, stages, x: torch.Tensor, pad_stride2: bool) -> torch.Tensor:
     """The nn.Sequential walk of sd/encoder.py:95-131 / sd/decoder.py:342-374 over the stage table."""
-    for i, op in enumerate(stages):
+    for i, tok in enumerate(stages):
         p = str(i)
+        op = parse_stage(tok)
         if op[0] == "conv":
             _, _cin, _cout, _ks, stride, pad = op
             if pad_stride2 and stride == 2:
@@ -70,14 +108,14 @@ def _run(sd: SD, stages, x: torch.Tensor, pad_stride2: bool) -> torch.Tensor:
 def vae_decode(sd: SD, latents: torch.Tensor) -> torch.Tensor:
     """(B,4,h,w) -> (B,3,8h,8w); divides the caller's tensor by 0.18215 IN PLACE like sd/decoder.py:364."""
     latents /= 0.18215
-    return _run(sd, arch.VAE_DECODER, latents, pad_stride2=False)
+    return _run(sd, DECODER_STAGES, latents, pad_stride2=False)
 
 
 @torch.no_grad()
 def vae_encode(sd: SD, image: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     """(B,3,H,W) in [-1,1], noise (B,4,H/8,W/8) -> latents (sd/encoder.py:95-155: clamp, exp, sqrt, reparameterise,
     x0.18215)."""
-    x = _run(sd, arch.VAE_ENCODER, image, pad_stride2=True)
+    x = _run(sd, ENCODER_STAGES, image, pad_stride2=True)
     mean, log_variance = torch.chunk(x, 2, dim=1)
     log_variance = torch.clamp(log_variance, -30, 20)
     stdev = log_variance.exp().sqrt()
@@ -93,13 +131,13 @@ def clip_forward(sd: SD, tokens: torch.Tensor) -> torch.Tensor:
     tokens = tokens.type(torch.long)
     x = F.embedding(tokens, sd["embedding.token_embedding.weight"]) + sd["embedding.position_embedding"]
     b, s, c = x.shape
-    hd = c // arch.CLIP_HEADS
+    hd = c // CLIP_HEADS
     mask = torch.ones((s, s), dtype=torch.bool, device=x.device).triu(1)
-    for i in range(arch.CLIP_LAYERS):
+    for i in range(CLIP_LAYERS):
         p = f"layers.{i}"
         h = F.layer_norm(x, (c,), sd[f"{p}.layernorm_1.weight"], sd[f"{p}.layernorm_1.bias"])
         qkv = F.linear(h, sd[f"{p}.attention.in_proj.weight"], sd[f"{p}.attention.in_proj.bias"])
-        q, k, v = (t.reshape(b, s, arch.CLIP_HEADS, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        q, k, v = (t.reshape(b, s, CLIP_HEADS, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
         w = (q @ k.transpose(-1, -2)).masked_fill(mask, float("-inf")) / math.sqrt(hd)   # mask before scale
         o = (torch.softmax(w, dim=-1) @ v).transpose(1, 2).reshape(b, s, c)
         x = x + F.linear(o, sd[f"{p}.attention.out_proj.weight"], sd[f"{p}.attention.out_proj.bias"])

@@ -158,3 +158,23 @@ def test_oracle_stage_tables_match_the_product():
     assert norm(unet_ref.ENCODERS) == norm(arch.ENCODERS)
     assert [tuple(op) for op in unet_ref.BOTTLENECK] == [tuple(op) for op in arch.BOTTLENECK]
     assert norm(unet_ref.DECODERS) == norm(arch.DECODERS)
+
+
+def test_aux_oracle_stage_tables_match_the_product():
+    """The VAE / CLIP oracle (oracle/aux_ref.py) carries its own statement of the two nn.Sequential bodies (sd/encoder.py:56-92,
+    sd/decoder.py:235-339) and of CLIP's sizes; it imports nothing from the product.  The two copies must agree."""
+    import ast
+    import os
+    from oracle import aux_ref
+    from pytorch_stable_diffusion_amd import arch
+    assert [aux_ref.parse_stage(t) for t in aux_ref.ENCODER_STAGES] == [tuple(op) for op in arch.VAE_ENCODER]
+    assert [aux_ref.parse_stage(t) for t in aux_ref.DECODER_STAGES] == [tuple(op) for op in arch.VAE_DECODER]
+    assert (aux_ref.CLIP_LAYERS, aux_ref.CLIP_HEADS) == (arch.CLIP_LAYERS, arch.CLIP_HEADS)
+    # no module under oracle/ imports the product package
+    odir = os.path.dirname(aux_ref.__file__)
+    for fn in sorted(os.listdir(odir)):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(odir, fn)).read())
+            for node in ast.walk(tree):
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+                assert not any(n.startswith("pytorch_stable_diffusion_amd") for n in names), f"oracle/{fn} imports the product"
