@@ -81,9 +81,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const
 // implements latents.repeat(2,1,1,1) of sd/pipeline.py:221 without a copy), output NHWC.
 // w36: [36][Cout] fp32 with k = (kh*3+kw)*4 + ci.
 // A lane is a pixel, a wave takes `cpw` chunks of 8 output channels for its 64 pixels: the pixel's 3x3 x Cin neighbourhood
-// is loaded once (<= 36 loads in flight, zeros outside the map) and the weights are wave-uniform, so they come through
-// the scalar cache (s_load_dwordx8) instead of 36 x 32 B per thread through the texture path -- the form with a thread per
-// (pixel, chunk) spent 18 us a step on exactly that traffic.  Products are added in (kh, kw, ci) order onto the bias, as before.
+// is loaded once (<= 36 loads in flight, zeros outside the map) and the weights are wave-uniform: staged once per wave in LDS and
+// read as broadcasts (the form with a thread per (pixel, chunk) read 36 x 32 B per thread through the texture path, the form with
+// scalar loads waited for a chain of scalar-cache misses: 18 us a step either way).  Products are added in (kh, kw, ci) order onto
+// the bias, as before.
+constexpr int STEM_CPW_MAX = 8;      // chunks of 8 output channels per wave (36 KiB of weights in LDS per workgroup at Cin = 4)
 template <int CIN>
 __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restrict__ lat, int lat_batch, const float* __restrict__ w36,
                                                         const float* __restrict__ bias, void* out, int out_f32, f16* out16,
@@ -116,20 +118,34 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restri
     }
   }
   const int C8 = Cout / 8;
-  const int c_end = min(C8, (chunk + 1) * cpw);
-  for (int c8 = chunk * cpw; c8 < c_end; ++c8) {
+  const int c_begin = chunk * cpw, c_end = min(C8, (chunk + 1) * cpw);
+  // this wave's weights -> its own LDS region as [chunk of 8 channels][k][8] (coalesced 32-byte runs of w36); the products below
+  // then read them as wave-wide broadcasts.  (Straight from memory the 36 x 32 B per chunk are a chain of scalar-cache misses.)
+  __shared__ __attribute__((aligned(16))) float s_w[4][STEM_CPW_MAX * 36 * CIN / 4 * 8];
+  float* sw = s_w[threadIdx.x >> 6];
+  {
+    const int nc = (c_end - c_begin) * 8, nk = 9 * CIN;
+    for (int idx = lane; idx < nk * nc; idx += 64) {
+      const int k = idx / nc, c = idx - k * nc;
+      sw[((c >> 3) * nk + k) * 8 + (c & 7)] = w36[(unsigned)(k * Cout + c_begin * 8 + c)];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // same wave reads what its lanes wrote: LDS ops of a wave are in order
+  }
+  for (int c8 = c_begin; c8 < c_end; ++c8) {
     f32x2 a2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a2[j] = *(const f32x2*)(bias + c8 * 8 + 2 * j);
+    const float* wc = sw + (c8 - c_begin) * 9 * CIN * 8;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci) {
-          const f32x2* wp = (const f32x2*)(w36 + (unsigned)((t * Cin + ci) * Cout + c8 * 8));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) a2[j] = __builtin_elementwise_fma(xv[t][ci], wp[j], a2[j]);
-        }
-      __builtin_amdgcn_sched_barrier(0);       // one tap's 32 weight SGPRs at a time (all 288 hoisted would spill into VGPRs)
+        const f32x4 w0 = *(const f32x4*)(wc + (t * CIN + ci) * 8), w1 = *(const f32x4*)(wc + (t * CIN + ci) * 8 + 4);
+        a2[0] = __builtin_elementwise_fma(xv[t][ci], f32x2{w0[0], w0[1]}, a2[0]);
+        a2[1] = __builtin_elementwise_fma(xv[t][ci], f32x2{w0[2], w0[3]}, a2[1]);
+        a2[2] = __builtin_elementwise_fma(xv[t][ci], f32x2{w1[0], w1[1]}, a2[2]);
+        a2[3] = __builtin_elementwise_fma(xv[t][ci], f32x2{w1[2], w1[3]}, a2[3]);
+      }
     }
     float acc[8];
 #pragma unroll
@@ -558,7 +574,7 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
   const int C8 = Cout / 8;
   const size_t groups = (npix + 63) / 64;
   // chunks of 8 channels per wave: as many as keeps >= ~2048 waves in the launch (the neighbourhood loads are per wave)
-  const int cpw = (int)std::max<size_t>(1, std::min<size_t>((size_t)C8, (size_t)C8 * groups / 2048));
+  const int cpw = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)C8, STEM_CPW_MAX), (size_t)C8 * groups / 2048));
   const int nchunk = (C8 + cpw - 1) / cpw;
   const size_t waves = groups * nchunk;
   const dim3 grid((unsigned)((waves + 3) / 4));
