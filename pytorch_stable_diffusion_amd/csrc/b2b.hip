@@ -198,6 +198,20 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
       // lane (half, g): chunks j = half, half + 2, ... of group g, two interleaved fp64 chains (a single 128-long chain of
       // dependent fp64 adds cost ~2 us at the start of every workgroup); the halves meet through one shuffle
       double gs0 = 0.0, gq0 = 0.0, gs1 = 0.0, gq1 = 0.0;
+      if (p.gn_parts == 2) {
+        // the producers' statistics records (GnRec, parts = 2: an entry is two {sum, sum of squares} pairs): same order of additions
+        // per entry as gn_apply_kernel's (pair 0 + pair 1), entries chunk by chunk
+        const float* pp = p.gn_partial + ((size_t)img * p.gn_nchunk * 32 + (lane & 31)) * 4;
+#pragma unroll 4
+        for (int j = lane >> 5; j < p.gn_nchunk; j += 4) {
+          const f32x4 t = *(const f32x4*)(pp + (size_t)j * 128);
+          gs0 += (double)t[0] + (double)t[2]; gq0 += (double)t[1] + (double)t[3];
+          if (j + 2 < p.gn_nchunk) {
+            const f32x4 u = *(const f32x4*)(pp + (size_t)(j + 2) * 128);
+            gs1 += (double)u[0] + (double)u[2]; gq1 += (double)u[1] + (double)u[3];
+          }
+        }
+      } else {
       const float* pp = p.gn_partial + ((size_t)img * p.gn_nchunk * 32 + (lane & 31)) * 2;
 #pragma unroll 4
       for (int j = lane >> 5; j < p.gn_nchunk; j += 4) {
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
           const f32x2 u = *(const f32x2*)(pp + (size_t)(j + 2) * 64);
           gs1 += (double)u[0]; gq1 += (double)u[1];
         }
+      }
       }
       double gs = gs0 + gs1, gq = gq0 + gq1;
       gs += __shfl_xor(gs, 32);

@@ -278,6 +278,7 @@ struct B2bArgs {
   // images of S rows); a1 is unused.
   const void* gx; int gx_f32;
   const float* gn_partial; int gn_nchunk; const float* gn_gamma; const float* gn_beta; float gn_eps;
+  int gn_parts;            // 0 / 1: gn_partial holds {sum, sum of squares} per (chunk, group); 2: two such pairs per entry (GnRec records with parts = 2)
   int* ln_guard; float ln_guard_thr2;     // as GemmArgs::ln_guard, for the rows of S
   GnRec gacc;                     // GroupNorm statistics of `out` (npass2 == 1 only; rows_img = pixels per image, mod = M, T = rows_img / 32, parts = 1)
 };
@@ -351,9 +352,11 @@ int sdmi_launch_cast_any_f32(const void* x, int in_f32, float* y, size_t n, hipS
 // y[m][n] = sum_k act(x[m][k]) * W[n][k] + b[n]   (fp32 x/y, fp16 W), act = SiLU if silu
 int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float* y, int M, int N, int K,
                              int silu, int ldy, hipStream_t st);
-// stem conv 4->Cout from NCHW fp32 latents (batch-broadcast when lat_batch == 1)
+// stem conv 4->Cout from NCHW fp32 latents (image b reads latent b mod lat_batch); gn_rec: GroupNorm statistics records of the
+// output (GnRec layout, atom 10, parts 1, gn_rec_T = H*W/64 record rows per image), or nullptr
 int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias,
-                          void* out, int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st);
+                          void* out, int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st,
+                          float* gn_rec = nullptr, int gn_rec_T = 0);
 // final conv Cin->4 from NHWC fp16 (already GN+SiLU) to NCHW fp32
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W,
                            int Cin, int Cout, hipStream_t st);

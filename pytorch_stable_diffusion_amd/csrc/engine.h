@@ -973,7 +973,7 @@ struct Engine {
   // conv_input, then layernorm_1 + in_proj (q | k | v, V transposed for the attention kernel) as one launch (b2b.hip)
   // gn != null: a1 is the RAW stream and the block's GroupNorm (statistics already in gn_partial) is applied inside the kernel
   int b2b_qkv(const Act& a1, const NormW* gn, const ConvW& w1, const Act& s_out, const FoldW& f2, float cscale, const Act& qk,
-              f16* vt, int S, int ldt) {
+              f16* vt, int S, int ldt, bool from_records = false) {
     TRY(flush_pending());
     B2bArgs t;
     memset(&t, 0, sizeof(t));
@@ -981,6 +981,9 @@ struct Engine {
     if (gn) {
       t.gx = a1.f ? (const void*)a1.f : (const void*)a1.h; t.gx_f32 = a1.f != nullptr;
       t.gn_partial = gn_partial; t.gn_nchunk = sdmi_gn_nchunk(S); t.gn_gamma = gn->gamma; t.gn_beta = gn->beta; t.gn_eps = 1e-6f;
+      if (from_records) {      // the statistics its producer left with the tensor (one 10-channel atom = one group at C = 320)
+        t.gn_partial = a1.grec; t.gn_nchunk = a1.gT; t.gn_parts = a1.gparts;
+      }
     }
     t.s32 = s_out.f; t.s16 = s_out.h;
     t.w2 = f2.w; t.K2 = 320; t.h2 = f2.h; t.cscale = cscale;
@@ -1058,7 +1061,15 @@ struct Engine {
     // Parity-green and measured time-neutral on one MI355X (same box: 4.173 vs 4.171 ms/step, 5 launches and 0.05 GB of
     // traffic fewer): the kernel's start-up takes what the 8.8 us gn_apply gave back, so the default keeps gn_apply.
     static const bool b2b_gn_on = getenv("SDMI_B2B_GN") && atoi(getenv("SDMI_B2B_GN")) != 0;
-    if (use_b2b && b2b_qkv_on && S % 32 == 0 && b2b_gn_on) {
+    // With the producer's statistics records at hand (x.gok) neither the statistics launch nor gn_apply is needed: the kernel
+    // sums the records of its image (T x 32 entries) in its prologue and normalises its rows into the A panels.  Same box,
+    // interleaved: 253.5 / 253.3 -> 254.9 / 255.3 steps/s, 251 -> 246 launches (the three-pass launch grows 32.5 -> 35.5 us,
+    // five gn_apply launches of 8.4 us go).  SDMI_B2B_GN_REC=0 keeps gn_apply.
+    static const bool b2b_gn_rec_on = !(getenv("SDMI_B2B_GN_REC") && atoi(getenv("SDMI_B2B_GN_REC")) == 0);
+    const bool gn_from_rec = b2b_gn_rec_on && x.gok && x.grec && kGnAtom == C / 32 && !pend;
+    if (use_b2b && b2b_qkv_on && S % 32 == 0 && gn_from_rec) {
+      TRY(b2b_qkv(x, &w.gn, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad, true));
+    } else if (use_b2b && b2b_qkv_on && S % 32 == 0 && b2b_gn_on) {
       // groupnorm + conv_input + layernorm_1 + in_proj: statistics launch, then everything else in the back-to-back kernel
       TRY(gn_stats(x, nullptr));
       TRY(b2b_qkv(x, &w.gn, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));

@@ -3,6 +3,7 @@
 //   fp32 latents directly, the 320->4 output conv that writes NCHW fp32, and the fused
 //   classifier-free-guidance combine + DDPM ancestral step.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -86,10 +87,12 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const
 // scalar loads waited for a chain of scalar-cache misses: 18 us a step either way).  Products are added in (kh, kw, ci) order onto
 // the bias, as before.
 constexpr int STEM_CPW_MAX = 8;      // chunks of 8 output channels per wave (36 KiB of weights in LDS per workgroup at Cin = 4)
-template <int CIN>
+// GACC: the wave also leaves the GroupNorm statistics of what it stores (GnRec, common.h): it then takes exactly 5 chunks = 40
+// channels = four 10-channel atoms for its 64 pixels, so a record (64-pixel row block, atom) is one wave's business.
+template <int CIN, bool GACC>
 __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restrict__ lat, int lat_batch, const float* __restrict__ w36,
                                                         const float* __restrict__ bias, void* out, int out_f32, f16* out16,
-                                                        int B, int H, int W, int Cout, int cpw, int nchunk) {
+                                                        int B, int H, int W, int Cout, int cpw, int nchunk, float* rec, int rec_T) {
   constexpr int Cin = CIN;
   const int lane = threadIdx.x & 63;
   const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restri
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // same wave reads what its lanes wrote: LDS ops of a wave are in order
   }
-  for (int c8 = c_begin; c8 < c_end; ++c8) {
+  float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};     // GACC: moments of the wave's four atoms, this lane's pixel
+  auto do_chunk = [&](int c8, auto JJ) {
+    constexpr int jj = decltype(JJ)::value;        // chunk index inside the wave's 40 channels (GACC: compile-time atom of every column)
     f32x2 a2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a2[j] = *(const f32x2*)(bias + c8 * 8 + 2 * j);
@@ -150,7 +155,11 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restri
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc[2 * j] = a2[j][0]; acc[2 * j + 1] = a2[j][1]; }
-    if (!live) continue;
+    if (!live) return;
+    if (GACC) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gs[(jj * 8 + e) / 10] += acc[e]; gq[(jj * 8 + e) / 10] += acc[e] * acc[e]; }
+    }
     f16x8 o16;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o16[e] = (f16)acc[e];
@@ -163,6 +172,27 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float* __restri
     } else {
       *(f16x8*)((f16*)out + off) = o16;
     }
+  };
+  if (GACC) {
+    // cpw == 5 (launcher): chunks jj = 0 .. 4 of the wave's 40 channels, unrolled so every column's atom is a constant
+    do_chunk(c_begin + 0, std::integral_constant<int, 0>{});
+    do_chunk(c_begin + 1, std::integral_constant<int, 1>{});
+    do_chunk(c_begin + 2, std::integral_constant<int, 2>{});
+    do_chunk(c_begin + 3, std::integral_constant<int, 3>{});
+    do_chunk(c_begin + 4, std::integral_constant<int, 4>{});
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { gs[a] += __shfl_xor(gs[a], o); gq[a] += __shfl_xor(gq[a], o); }
+    if (lane == 0) {
+      const unsigned hw = (unsigned)H * W, p0 = grp * 64u;            // (H * W a multiple of 64: the block lies in one image)
+      const unsigned img = p0 / hw, t_row = (p0 - img * hw) >> 6;
+      f32x2* r = (f32x2*)rec + ((size_t)img * rec_T + t_row) * (Cout / 10) + chunk * 4;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) r[a] = f32x2{gs[a], gq[a]};
+    }
+  } else {
+    for (int c8 = c_begin; c8 < c_end; ++c8) do_chunk(c8, std::integral_constant<int, 0>{});
   }
 }
 
@@ -567,23 +597,30 @@ int sdmi_launch_small_linear(const float* x, const f16* w, const float* b, float
 }
 
 int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, const float* bias, void* out,
-                          int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st) {
+                          int out_f32, f16* out16, int B, int H, int W, int Cout, int Cin, hipStream_t st, float* gn_rec, int gn_rec_T) {
   SDMI_REQUIRE(Cout % 8 == 0 && Cin >= 1 && Cin <= 4, "stem conv: Cout=%d Cin=%d", Cout, Cin);
   const size_t npix = (size_t)B * H * W;
   SDMI_REQUIRE(npix * Cout < ((size_t)1 << 31), "stem conv: too many outputs");
   const int C8 = Cout / 8;
   const size_t groups = (npix + 63) / 64;
   // chunks of 8 channels per wave: as many as keeps >= ~2048 waves in the launch (the neighbourhood loads are per wave)
-  const int cpw = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)C8, STEM_CPW_MAX), (size_t)C8 * groups / 2048));
+  int cpw = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)C8, STEM_CPW_MAX), (size_t)C8 * groups / 2048));
+  if (gn_rec) {
+    // GroupNorm statistics records (one per 64-pixel row block and 10-channel atom, parts = 1): a wave owns 40 channels
+    SDMI_REQUIRE(Cin == 4 && Cout % 40 == 0 && (H * W) % 64 == 0 && gn_rec_T == H * W / 64 && out_f32,
+                 "stem conv: statistics records need Cin = 4, Cout %% 40 == 0, H*W %% 64 == 0, T = H*W/64 (Cout=%d H=%d W=%d T=%d)", Cout, H, W, gn_rec_T);
+    cpw = 5;
+  }
   const int nchunk = (C8 + cpw - 1) / cpw;
   const size_t waves = groups * nchunk;
   const dim3 grid((unsigned)((waves + 3) / 4));
-#define SDMI_STEM(CI) hipLaunchKernelGGL(stem_conv_kernel<CI>, grid, dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32, out16, B, H, W, Cout, cpw, nchunk)
-  switch (Cin) {
-    case 1: SDMI_STEM(1); break;
-    case 2: SDMI_STEM(2); break;
-    case 3: SDMI_STEM(3); break;
-    default: SDMI_STEM(4); break;
+#define SDMI_STEM(CI, GA) hipLaunchKernelGGL((stem_conv_kernel<CI, GA>), grid, dim3(256), 0, st, lat, lat_batch, w36, bias, out, out_f32, out16, B, H, W, Cout, cpw, nchunk, gn_rec, gn_rec_T)
+  if (gn_rec) SDMI_STEM(4, true);
+  else switch (Cin) {
+    case 1: SDMI_STEM(1, false); break;
+    case 2: SDMI_STEM(2, false); break;
+    case 3: SDMI_STEM(3, false); break;
+    default: SDMI_STEM(4, false); break;
   }
 #undef SDMI_STEM
   SDMI_CHECK_HIP(hipGetLastError());

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     const int apg = cpg / p.atom, na0 = p.C0 / p.atom;
     const int Tmax = max(p.accT0, p.accT1);
     const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 16, ...
-    constexpr int MAXR = 8;                             // kGaccMaxRec (4096) records / 32 groups / 16 shares
+    constexpr int MAXR = 12;                            // in flight at once: 4096 records / 32 groups / 16 shares = 8 per source; a concat of a 128-row-block source and a 64-row-block one has 12; the loop below takes what is beyond
     f32x4 rv[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {

@@ -377,8 +377,12 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
   }
   Act x;
   TRY(u->new_act(batch, h, w, u->stem_cout, true, &x));
+  // the stem leaves the GroupNorm statistics of its output too (encoders.1.0's groupnorm_feature and, through the skip, the last
+  // decoder stage's concat GroupNorm read them: sd/diffusion.py:173,671)
+  const bool stem_rec = x.grec && x.f && u->stem_cout % 40 == 0 && (h * w) % 64 == 0 && (h * w / 64) * (u->stem_cout / kGnAtom) <= kGnRecMax;
   TRY(sdmi_launch_stem_conv(latents_dev, latent_batch, u->stem_w36, u->stem_bias, x.f ? (void*)x.f : (void*)x.h,
-                            x.f != nullptr, x.f ? x.h : nullptr, batch, h, w, u->stem_cout, 4, u->st));
+                            x.f != nullptr, x.f ? x.h : nullptr, batch, h, w, u->stem_cout, 4, u->st, stem_rec ? x.grec : nullptr, h * w / 64));
+  if (stem_rec) { x.gok = true; x.gT = h * w / 64; x.gparts = 1; }
   u->launches += 1;
   u->log_launch("stem");
   std::vector<Act> skips;
