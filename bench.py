@@ -180,7 +180,7 @@ def main():
     # backend, an all-reduce of 1 over the group, every rank's own steps/s, and the start-up weight broadcast
     group_facts = replicas.group_facts(args.steps / my_elapsed, device=dev)
     group_facts["weight_broadcast"] = bcast
-    launches = h.last_launch_count + 1
+    launches = h.last_launch_count                 # every kernel of the step: the forward's and the (fused) sampler step
 
     # ---- roofline: per-launch HIP events on the forward's own stream, same process, after the timed region.
     # ONE family definition everywhere (this line, tools/join_trace.py, profiles/r04_*): "mfma" = the GEMM kernels that run
@@ -214,7 +214,7 @@ def main():
         # (tools/profile_round.sh; FETCH_SIZE x2: gfx950 correction), committed under profiles/.  They are only quoted when
         # that profile saw the launch structure this run has (same launches per step): a profile of other kernels is refused
         # rather than reported stale.
-        launches_now = h.last_launch_count + 1
+        launches_now = h.last_launch_count
         traffic = traffic_fin = traffic_step = mfma_busy = None
         traffic_src = mfma_src = None
         tpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic_by_shape.json")
@@ -250,7 +250,7 @@ def main():
         if hw == 64 and os.path.exists(jpath):
             with open(jpath) as jf:
                 jj = json.load(jf)
-            if jj.get("kernels_per_step") == launches_now - 1:
+            if jj.get("kernels_per_step") == launches_now:
                 rocprof = {"achieved": jj["mfma"]["tflops"], "frac": round(jj["mfma"]["tflops"] / PEAK_TFLOPS_F16, 4),
                            "ms_per_step": jj["mfma"]["ms"], "source": f"profiles/{PROFILE_TAG}_step_families.json (rocprofv3 --kernel-trace of bench.py, one step)"}
         roof = {
@@ -363,7 +363,7 @@ def main():
         torch.cuda.synchronize()
         dtb = time.perf_counter() - tb0
         batched = {"prompts": P, "unet_batch": 2 * P, "steps_per_s_aggregate": round(P * args.steps / dtb, 3),
-                   "ms_per_batched_step": round(dtb / args.steps * 1e3, 3), "launches_per_batched_step": h.last_launch_count + 1,
+                   "ms_per_batched_step": round(dtb / args.steps * 1e3, 3), "launches_per_batched_step": h.last_launch_count,
                    "first_step_s": round(t_first_p, 2), "gemm_shapes_tuned_in_process": h.tuned_shapes - tuned_shapes,
                    "note": "P independent prompts (own latents, noise stream, contexts) through one chain of launches at UNet batch "
                            "2P (pipeline.generate_batch / replicas.run_prompts(batch_per_gpu=P) are the generate()-level forms); "

@@ -360,6 +360,10 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
 // final conv Cin->4 from NHWC fp16 (already GN+SiLU) to NCHW fp32
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W,
                            int Cin, int Cout, hipStream_t st);
+// the same conv for prompt i's conditional (b = i) and unconditional (b = P + i) image + CFG combine + DDPM update of the latents
+// (P,4,H,W) in one launch (the eps tensor is never written); coef as sdmi_launch_cfg_ddpm
+int sdmi_launch_final_conv_step(const f16* x, const f16* w, const float* bias, int P, int H, int W, int Cin, int do_cfg, float cfg_scale,
+                                float* latents, const float* noise, const float* coef, hipStream_t st);
 int sdmi_launch_row_softmax(const f16* s, f16* p, int rows, int L, float scale, hipStream_t st);
 int sdmi_launch_q4_reinterpret_add(const float* o, const void* x, int x_f32, void* y, int y_f32, f16* y16, int B, int P,
                                    int C, hipStream_t st);

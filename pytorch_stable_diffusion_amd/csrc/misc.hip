@@ -274,30 +274,112 @@ struct DdpmCoef { float sqrt_beta_prod, sqrt_alpha_prod, c0, ct, sigma; int has_
 // CFG combine (sd/pipeline.py:230-233, cond first) + ancestral DDPM step (sd/ddpm.py:116-137).
 // Operation order and rounding follow the reference's fp32 tensor expression exactly (no FMA
 // contraction), so with identical eps the result is bit-identical to the reference step.
+__device__ __forceinline__ float cfg_combine(float e, float eu, float cfg_scale) {
+#pragma clang fp contract(off)
+  const float d = e - eu;
+  const float sd = cfg_scale * d;
+  return sd + eu;
+}
+__device__ __forceinline__ float ddpm_prev(float e, float x, float nz, const DdpmCoef& k) {
+#pragma clang fp contract(off)
+  const float t1 = k.sqrt_beta_prod * e;
+  const float t2 = x - t1;
+  const float x0 = t2 / k.sqrt_alpha_prod;
+  const float a = k.c0 * x0;
+  const float bb = k.ct * x;
+  float prev = a + bb;
+  if (k.has_noise) {
+    const float v = k.sigma * nz;
+    prev = prev + v;
+  }
+  return prev;
+}
 __global__ __launch_bounds__(256) void cfg_ddpm_kernel(const float* eps, int do_cfg, float cfg_scale, float* latents,
                                                        const float* noise, DdpmCoef k, size_t n, float* eps_out) {
-#pragma clang fp contract(off)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float e = eps[i];
-    if (do_cfg) {
-      const float eu = eps[n + i];
-      const float d = e - eu;
-      const float sd = cfg_scale * d;
-      e = sd + eu;
-    }
+    if (do_cfg) e = cfg_combine(e, eps[n + i], cfg_scale);
     if (eps_out) eps_out[i] = e;
-    const float x = latents[i];
-    const float t1 = k.sqrt_beta_prod * e;
-    const float t2 = x - t1;
-    const float x0 = t2 / k.sqrt_alpha_prod;
-    const float a = k.c0 * x0;
-    const float bb = k.ct * x;
-    float prev = a + bb;
-    if (k.has_noise) {
-      const float v = k.sigma * noise[i];
-      prev = prev + v;
+    latents[i] = ddpm_prev(e, latents[i], k.has_noise ? noise[i] : 0.f, k);
+  }
+}
+
+// The step's last two launches as one (round 4): the output conv (Cin -> 4, above) of prompt i's conditional image b = i and
+// unconditional image b = P + i for four pixels per wave, then the guidance combine and the DDPM update of those 16 latents by
+// the wave itself -- the eps tensor never reaches memory.  Per image the sums are taken exactly as final_conv_kernel takes them
+// (same items per lane, same reduction), the arithmetic behind them is cfg_combine / ddpm_prev: bit-identical to the two launches.
+__global__ __launch_bounds__(256) void final_conv_step_kernel(const f16* x, const f16* w, const float* bias, int P, int H, int W, int Cin,
+                                                              int do_cfg, float cfg_scale, float* latents, const float* noise, DdpmCoef k) {
+  constexpr int NCO = 4;
+  const int lane = threadIdx.x & 63;
+  const unsigned grp = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const unsigned ngrp = (unsigned)P * H * W / FC_PX;
+  if (grp >= ngrp) return;
+  const unsigned pix0 = grp * FC_PX;
+  const unsigned prow = pix0 / (unsigned)W;
+  const int ow0 = (int)(pix0 - prow * W);
+  const int b = (int)(prow / (unsigned)H);                   // prompt index
+  const int oh = (int)(prow - (unsigned)b * H);
+  const int C8 = Cin / 8;
+  const int items = 9 * C8;
+  // both images in ONE item loop (their loads fly together); per image the items, their order and the reduction are
+  // final_conv_kernel's, so each sum has that kernel's bits
+  float acc[2][FC_PX][NCO];
+#pragma unroll
+  for (int im = 0; im < 2; ++im)
+#pragma unroll
+    for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) acc[im][px][co] = 0.f;
+  const int nim = do_cfg ? 2 : 1;
+  for (int it = lane; it < items; it += 64) {
+    const int tap = it / C8, c8 = it - tap * C8;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int ih = oh + kh - 1;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    f16x8 wv[NCO];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) wv[co] = *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8);
+    f16x8 xv[2][FC_PX];
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int px = 0; px < FC_PX; ++px) {
+        const int iw = ow0 + px + kw - 1;
+        xv[im][px] = (im < nim && (unsigned)iw < (unsigned)W) ? *(const f16x8*)(x + (((size_t)(b + im * P) * H + ih) * W + iw) * Cin + c8 * 8) : f16x8{};
+      }
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+        for (int co = 0; co < NCO; ++co)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2)
+            acc[im][px][co] = __builtin_amdgcn_fdot2(f16x2{xv[im][px][e], xv[im][px][e + 1]}, f16x2{wv[co][e], wv[co][e + 1]}, acc[im][px][co], false);
+  }
+  float eps[2][FC_PX][NCO];
+#pragma unroll
+  for (int im = 0; im < 2; ++im)
+#pragma unroll
+    for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[im][px][co] += __shfl_xor(acc[im][px][co], o);
+        eps[im][px][co] = acc[im][px][co] + bias[co];
+      }
+  if (lane == 0) {
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      const size_t o = (((size_t)b * NCO + co) * H + oh) * W + ow0;      // latents / noise: NCHW (P, 4, H, W)
+#pragma unroll
+      for (int px = 0; px < FC_PX; ++px) {
+        float e = eps[0][px][co];
+        if (do_cfg) e = cfg_combine(e, eps[1][px][co], cfg_scale);
+        latents[o + px] = ddpm_prev(e, latents[o + px], k.has_noise ? noise[o + px] : 0.f, k);
+      }
     }
-    latents[i] = prev;
   }
 }
 
@@ -650,6 +732,25 @@ int sdmi_launch_cfg_ddpm(const float* eps, int do_cfg, float cfg_scale, float* l
   k.has_noise = noise != nullptr;
   hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(nblocks(n, 256, 1024)), dim3(256), 0, st, eps, do_cfg, cfg_scale, latents,
                      noise, k, n, eps_out);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int sdmi_launch_final_conv_step(const f16* x, const f16* w, const float* bias, int P, int H, int W, int Cin, int do_cfg, float cfg_scale,
+                                float* latents, const float* noise, const float* coef, hipStream_t st) {
+  SDMI_REQUIRE(Cin % 8 == 0 && W % FC_PX == 0 && P >= 1, "final conv + step: Cin=%d W=%d P=%d", Cin, W, P);
+  const size_t npix = (size_t)P * H * W;
+  SDMI_REQUIRE(npix * 2 < ((size_t)1 << 31), "final conv + step: too many pixels");
+  DdpmCoef k;
+  k.sqrt_beta_prod = coef[0];
+  k.sqrt_alpha_prod = coef[1];
+  k.c0 = coef[2];
+  k.ct = coef[3];
+  k.sigma = coef[4];
+  k.has_noise = noise != nullptr;
+  const size_t ngrp = npix / FC_PX;
+  hipLaunchKernelGGL(final_conv_step_kernel, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, P, H, W, Cin, do_cfg, cfg_scale,
+                     latents, noise, k);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -147,10 +147,20 @@ int run_stage(sdmi_unet* u, const std::string& grp_prefix, const Stage& stage, A
   return SDMI_OK;
 }
 
-int final_layer(sdmi_unet* u, const Act& x, float* eps_out) {
+// the sampler step fused behind the output conv (sdmi_unet_denoise_step_batch): latents (P,4,h,w) updated in place
+struct StepFuse { float* latents; const float* noise; const float* coef; int n_prompts, do_cfg; float cfg_scale; };
+
+int final_layer(sdmi_unet* u, const Act& x, float* eps_out, const StepFuse* sf = nullptr) {
   if (!u->has_final) { sdmi_set_error("final layer not loaded"); return SDMI_ENOENT; }
   Act t;
   TRY(u->groupnorm(x, nullptr, u->final_gn, 1e-5f, 1, &t));
+  if (sf) {
+    TRY(sdmi_launch_final_conv_step(t.h, u->final_conv.w, u->final_conv.bias, sf->n_prompts, x.H, x.W, x.C, sf->do_cfg, sf->cfg_scale,
+                                    sf->latents, sf->noise, sf->coef, u->st));
+    u->launches += 1;
+    u->log_launch("final_conv");
+    return SDMI_OK;
+  }
   TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, 4, u->st));
   u->launches += 1;
   u->log_launch("final_conv");
@@ -356,9 +366,9 @@ int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, voi
   return SDMI_OK;
 }
 
-int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev, int step_idx,
-                      float* eps_out_dev, int batch, int h, int w, void* stream) {
-  if (!u || !latents_dev || !eps_out_dev) { sdmi_set_error("forward: null argument"); return SDMI_EINVAL; }
+static int unet_forward_impl(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev, int step_idx,
+                             float* eps_out_dev, int batch, int h, int w, void* stream, const StepFuse* sf) {
+  if (!u || !latents_dev || (!eps_out_dev && !sf)) { sdmi_set_error("forward: null argument"); return SDMI_EINVAL; }
   SDMI_REQUIRE(latent_batch >= 1 && batch % latent_batch == 0, "forward: latent_batch=%d must divide batch=%d", latent_batch, batch);
   SDMI_REQUIRE(h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "forward: latent size %dx%d must be multiples of 8", h, w);
   SDMI_REQUIRE(u->has_stem && u->has_final && u->has_time, "forward: incomplete weights (handle created with SDMI_FLAG_PARTIAL?)");
@@ -401,9 +411,14 @@ int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, 
     TRY(run_stage(u, "unet.decoders." + std::to_string(i), decoders()[i], x, &sk, tv, &y));
     x = y;
   }
-  TRY(final_layer(u, x, eps_out_dev));
+  TRY(final_layer(u, x, eps_out_dev, sf));
   u->write_launch_log();
   return SDMI_OK;
+}
+
+int sdmi_unet_forward(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev, int step_idx,
+                      float* eps_out_dev, int batch, int h, int w, void* stream) {
+  return unet_forward_impl(u, latents_dev, latent_batch, temb_dev, step_idx, eps_out_dev, batch, h, w, stream, nullptr);
 }
 
 int sdmi_cfg_ddpm_step(const float* eps_dev, int do_cfg, float cfg_scale, float* latents_dev, const float* noise_dev,
@@ -432,6 +447,13 @@ int sdmi_unet_denoise_step_batch(sdmi_unet* u, float* latents_dev, int n_prompts
   if (u->eps_elems < need) {
     TRY(u->dmalloc(&u->eps_buf, need * 4));
     u->eps_elems = need;
+  }
+  // SDMI_STEP_FUSE=0: the output conv writes eps and cfg_ddpm_kernel makes the step (two launches; A/B and the bit-identity test)
+  static const bool fuse_on = !(getenv("SDMI_STEP_FUSE") && atoi(getenv("SDMI_STEP_FUSE")) == 0);
+  if (fuse_on && w % 4 == 0) {
+    if (!coef) { sdmi_set_error("denoise_step: null coefficients"); return SDMI_EINVAL; }
+    StepFuse sf{latents_dev, noise_dev, coef, n_prompts, do_cfg, cfg_scale};
+    return unet_forward_impl(u, latents_dev, n_prompts, nullptr, step_idx, nullptr, batch, h, w, stream, &sf);
   }
   TRY(sdmi_unet_forward(u, latents_dev, n_prompts, nullptr, step_idx, u->eps_buf, batch, h, w, stream));
   TRY(sdmi_launch_cfg_ddpm(u->eps_buf, do_cfg, cfg_scale, latents_dev, noise_dev, coef, (size_t)n_prompts * 4 * h * w, nullptr, (hipStream_t)stream));

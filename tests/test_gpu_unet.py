@@ -116,6 +116,35 @@ def test_cfg_batch_broadcast_equals_repeat(full_model):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n_prompts,do_cfg,with_noise", [(1, True, True), (1, True, False), (3, True, True), (2, False, True)])
+def test_fused_step_equals_forward_then_cfg_ddpm(full_model, n_prompts, do_cfg, with_noise):
+    """sdmi_unet_denoise_step(_batch) ends in ONE launch that makes the output conv, the guidance combine and the DDPM update
+    (final_conv_step_kernel); the two-launch form -- sdmi_unet_forward, then sdmi_cfg_ddpm_step (sd/pipeline.py:230-233,
+    sd/ddpm.py:116-137) -- must give the same latents bit for bit."""
+    from oracle import ddpm_ref
+    from pytorch_stable_diffusion_amd import _native as N
+    from pytorch_stable_diffusion_amd.ddpm import DDPMSampler
+    sampler = DDPMSampler(torch.Generator().manual_seed(0))
+    sampler.set_inference_timesteps(50)
+    ts = sampler.timesteps.tolist()
+    batch = n_prompts * (2 if do_cfg else 1)
+    ctx = H.seeded((batch, 77, 768), 31).to(DEV)
+    lat = H.seeded((n_prompts, 4, 16, 16), 32).to(DEV)
+    noise = H.seeded((n_prompts, 4, 16, 16), 33).to(DEV) if with_noise else None
+    full_model.set_context(ctx)
+    full_model.set_schedule(torch.cat([ddpm_ref.time_embedding(t) for t in ts]).to(DEV))
+    h = full_model.handle()
+    i = 7
+    coef = sampler.step_coefficients(ts[i])
+    eps = h.forward(lat, batch, step_idx=i)
+    two = lat.clone()
+    N.cfg_ddpm_step(eps, do_cfg, 7.5, two, noise, coef)
+    one = lat.clone()
+    h.denoise_step(one, i, do_cfg, 7.5, noise, coef)
+    assert torch.equal(one, two), f"max abs diff {(one - two).abs().max().item():.3e}"
+    assert not torch.equal(one, lat)
+
+
 def test_schedule_path_equals_adhoc_time(full_model):
     from oracle import ddpm_ref
     ctx = H.seeded((2, 77, 768), 1).to(DEV)

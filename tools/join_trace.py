@@ -9,7 +9,7 @@
   MFMA busy     : join_trace.py mfma <counter_collection.csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> <launch_log.txt> <out.json> [step_families.json]
                   (with the families file: the busy cycles also over the family's kernel time of the TRACE pass x 2.4 GHz)
 
-A step = the kernels from stem_conv to cfg_ddpm; log line i is matched to the i-th kernel of the step whose name fits the
+A step = the kernels from stem_conv to cfg_ddpm (or final_conv_step, which contains it); log line i is matched to the i-th kernel of the step whose name fits the
 line's kind (fill kernels of hipMemsetAsync and anything else unknown are skipped)."""
 import collections
 import csv
@@ -49,7 +49,7 @@ def read_log(path):
 def steps_of(rows):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "stem_conv" in r["Kernel_Name"]]
-    ends = [i for i, r in enumerate(rows) if "cfg_ddpm" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "cfg_ddpm" in r["Kernel_Name"] or "final_conv_step" in r["Kernel_Name"]]
     out = []
     for s in starts:
         e = next((x for x in ends if x > s), None)
