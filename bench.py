@@ -297,14 +297,23 @@ def main():
     # (BASELINE configs[3]) finishes sooner because the chains fill each other's per-launch latency.
     chains = None
     if rank == 0 and world == 1 and args.chains > 1:
+        # (with --batch-prompts P as well: every lane carries P prompts as one batched chain -- C x P prompts in flight)
+        PL = max(1, args.batch_prompts)
+        if PL > 1:
+            c_ctx = torch.cat([torch.randn((PL, 77, 768), generator=torch.Generator().manual_seed(21)),
+                               torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(22)).repeat(PL, 1, 1)]).to(dev)
+            c_lat0 = torch.randn((PL, 4, hw, hw), generator=torch.Generator().manual_seed(23)).to(dev)
+            c_noise = torch.randn((50, PL, 4, hw, hw), generator=torch.Generator().manual_seed(24)).to(dev)
+        else:
+            c_ctx, c_lat0, c_noise = ctx, lat0, noise
         lanes = model.lanes(args.chains)
         streams = [torch.cuda.Stream(device=dev) for _ in lanes]
         lats = []
         for k, (ln, stc) in enumerate(zip(lanes, streams)):
             with torch.cuda.stream(stc):
-                ln.set_context(ctx)
+                ln.set_context(c_ctx)
                 ln.set_schedule(temb)
-                lats.append(lat0.clone())
+                lats.append(c_lat0.clone())
         torch.cuda.synchronize()
 
         def run_chains(n_steps):
@@ -313,8 +322,8 @@ def main():
                 for ln, stc, lt in zip(lanes, streams, lats):
                     with torch.cuda.stream(stc):
                         if j == 0:
-                            lt.copy_(lat0)
-                        ln.handle().denoise_step(lt, j, True, 7.5, noise[j] if ts[j] > 0 else None, coefs[j])
+                            lt.copy_(c_lat0)
+                        ln.handle().denoise_step(lt, j, True, 7.5, c_noise[j] if ts[j] > 0 else None, coefs[j])
 
         run_chains(args.warmup)
         torch.cuda.synchronize()
@@ -322,7 +331,7 @@ def main():
         run_chains(args.steps)
         torch.cuda.synchronize()
         dtc = time.perf_counter() - tc0
-        chains = {"chains": args.chains, "steps_per_s_aggregate": round(args.chains * args.steps / dtc, 3),
+        chains = {"chains": args.chains, "prompts_per_chain": PL, "steps_per_s_aggregate": round(args.chains * PL * args.steps / dtc, 3),
                   "ms_per_step_per_chain": round(dtc / args.steps * 1e3, 3),
                   "note": "independent prompts on one GPU: lanes of one packed-weight arena (Diffusion.lane / sdmi_unet_clone), one "
                           "HIP stream each, steps enqueued alternately by one host thread; replicas.run_prompts(streams_per_gpu=C) "

@@ -322,3 +322,22 @@ def test_generate_batch_matches_single_prompt_runs(models):
     assert d0.max() <= U8_MAX and d0.mean() / 255.0 < PIXEL_MAE, f"prompt 0 vs the reference: max {d0.max()}, MAE {d0.mean() / 255:.2e}"
     with pytest.raises(ValueError):
         pipeline.generate_batch(["a"] * 9, seeds=list(range(9)), **kw)
+
+
+def test_run_prompts_lanes_of_batched_groups_match_one_lane(models):
+    """replicas.run_prompts(streams_per_gpu=2, batch_per_gpu=2): four prompts as two batched chains on two lanes at once give,
+    image for image, what the same two batched chains give one after the other on one lane (a lane runs the same kernels and
+    plans over the same packed weights: bit-identical)."""
+    from pytorch_stable_diffusion_amd import replicas
+    m = dict(models)
+    m["decoder"] = models["decoder"].inner
+    prompts = ["a dog", "a cat", "a red car by the sea", "a house"]
+    kw = dict(seed_base=11, n_inference_steps=4, height=256, width=256, batch_per_gpu=2)
+    one, s1 = replicas.run_prompts(prompts, m, StubTokenizer(), DEV, streams_per_gpu=1, **kw)
+    two, s2 = replicas.run_prompts(prompts, m, StubTokenizer(), DEV, streams_per_gpu=2, **kw)
+    assert s1["streams_per_gpu"] == 1 and s2["streams_per_gpu"] == 2 and s2["batch_per_gpu"] == 2
+    assert len(one) == len(two) == 4
+    for a, b in zip(one, two):
+        assert a.shape == (256, 256, 3) and torch.equal(a, b)
+    assert not torch.equal(two[0], two[1])
+    m["diffusion"].release_lanes()

@@ -227,3 +227,33 @@ def test_batch_per_gpu_groups_keep_prompt_order_and_seeds():
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", generate_batch=stub_batch, batch_per_gpu=2, input_images=[None] * 5)
+
+
+def test_lanes_of_batched_groups_keep_prompt_order_and_seeds():
+    """run_prompts(streams_per_gpu=2, batch_per_gpu=2): the rank's prompts form groups of two (one batched chain each) and the
+    groups are dealt to two lanes; every prompt is generated once, with its own seed, by the lane its group belongs to, and the
+    images come back in prompt order."""
+    import threading
+    from tests.stub_tokenizer import StubTokenizer
+    models = _stub_models(_stub_weights())
+    calls, lock = [], threading.Lock()
+
+    def stub_batch(prompts, uncond_prompt="", seeds=None, models=None, tokenizer=None, n_inference_steps=3, height=64, width=64,
+                   cfg_scale=7.5, **_):
+        with lock:
+            calls.append((list(prompts), list(seeds), threading.current_thread().name))
+        return [_stub_generate(prompt=p, uncond_prompt=uncond_prompt, models=models, seed=s, tokenizer=tokenizer,
+                               n_inference_steps=n_inference_steps, height=height, width=width, cfg_scale=cfg_scale)
+                for p, s in zip(prompts, seeds)]
+
+    one, _ = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64, width=64,
+                                  generate=_stub_generate)
+    two, st = replicas.run_prompts(_PROMPTS, models, StubTokenizer(), "cpu", seed_base=100, n_inference_steps=3, height=64, width=64,
+                                   generate=_stub_generate, generate_batch=stub_batch, batch_per_gpu=2, streams_per_gpu=2)
+    assert st["batch_per_gpu"] == 2 and st["streams_per_gpu"] == 2
+    by_group = {tuple(s): (p, t) for p, s, t in calls}
+    assert sorted(by_group) == [(100, 101), (102, 103), (104,)]
+    assert by_group[(100, 101)][0] == _PROMPTS[0:2] and by_group[(104,)][0] == _PROMPTS[4:5]
+    assert by_group[(100, 101)][1] == by_group[(104,)][1] == "sdmi-lane-0" and by_group[(102, 103)][1] == "sdmi-lane-1"
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)

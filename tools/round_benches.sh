@@ -14,6 +14,7 @@ python3 bench.py --chains 3 --steps 20 --warmup 5 --no-cpu-baseline --no-image-l
 for P in 2 4 6 8; do
   python3 bench.py --batch-prompts $P --steps 20 --warmup 5 --no-cpu-baseline --no-image-latency > $out/p$P.log 2> $out/p$P.err && last $out/p$P.log $out/${tag}_bench_batched_p$P.json
 done
+python3 bench.py --chains 2 --batch-prompts 6 --steps 20 --warmup 5 --no-cpu-baseline --no-image-latency > $out/c2p6.log 2> $out/c2p6.err && last $out/c2p6.log $out/${tag}_bench_lanes2_batched6.json
 # two ranks on the one GPU over gloo (rehearsal of the N > 1 path of bench.py: barriers, max over ranks, the self-check fields)
 SDMI_BENCH_ONE_DEVICE=1 SDMI_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-image-latency > $out/r2.log 2> $out/r2.err && last $out/r2.log $out/${tag}_bench_2rank_rehearsal.json
