@@ -104,6 +104,26 @@ def test_full_unet_vs_golden(full_model, hw, t):
     assert rel < UNET_REL_L2, f"{hw}x{hw} t={t}: rel L2 {rel:.2e}, max abs {mx:.2e}"
 
 
+@pytest.mark.parametrize("h,w", [(64, 96), (40, 24)])
+def test_full_unet_non_square_vs_oracle(full_model, h, w):
+    """Latent maps that are not square (the reference hard-codes 512x512, sd/pipeline.py:7-10; generate(height=, width=) of this
+    package takes any multiple of 64 pixels, the C ABI any multiple of 8 latents): 512x768 pixels and a ragged 320x192 against the
+    oracle on the same inputs (the halo-reuse conv kernels need whole image rows per tile and W % 8 == 0: other shapes fall
+    back to the generic kernel inside the same plan machinery)."""
+    from oracle import ddpm_ref, unet_ref
+    sd = H.full_weights()
+    ctx = H.seeded((2, 77, 768), 41)
+    lat = H.seeded((1, 4, h, w), 42).repeat(2, 1, 1, 1)
+    temb = ddpm_ref.time_embedding(620)
+    with torch.no_grad():
+        ref = unet_ref.diffusion_forward(sd, lat, ctx, temb)
+    out = full_model(lat.to(DEV), ctx.to(DEV), temb.to(DEV)).cpu()
+    rel = H.rel_l2(out, ref)
+    G.log_metric(test="full_unet_non_square", h=h, w=w, rel_l2=rel, launches=full_model.handle().last_launch_count)
+    assert out.shape == ref.shape == (2, 4, h, w)
+    assert rel < UNET_REL_L2, f"{h}x{w}: rel L2 {rel:.2e}"
+
+
 def test_cfg_batch_broadcast_equals_repeat(full_model):
     """latent_batch=1 with batch=2 (no copy) == explicit repeat(2,1,1,1) (sd/pipeline.py:221)."""
     from oracle import ddpm_ref
