@@ -204,6 +204,11 @@ typedef struct sdmi_gemm_desc {
   /* ln_guard != NULL (with ln_stat): every row whose |mean| exceeds ln_guard_sigma standard deviations adds 1 to *ln_guard
    * (the guard of the LayerNorm fold: sdmi_unet_ln_guard) */
   int* ln_guard; float ln_guard_sigma;
+  /* gna_rec != NULL: GroupNorm (32 groups, no SiLU; sd/diffusion.py:294-298) of the A operand applied inside the launch -- a0 is the RAW
+   * fp16 tensor, a plain 1x1 GEMM with K = c0 -- from the statistics records its producer left (layout as gacc above: gna_t record
+   * rows per image, gna_parts, atoms of gna_atom channels, gna_rows rows per image), gamma / beta [c0] fp32.  Configs built with the
+   * variant only (the "p" / "q2" rings with 64-row tiles); others fail with "cannot apply GroupNorm". */
+  const float* gna_rec; const float* gna_gamma; const float* gna_beta; float gna_eps; int gna_t, gna_parts, gna_atom, gna_rows;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* record rows per image (T) and parts of the statistics the launch described by d writes to d->gacc (d->gacc != NULL);

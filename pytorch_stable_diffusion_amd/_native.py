@@ -38,7 +38,9 @@ class GemmDesc(C.Structure):
                 ("vec_img_stride", C.c_int), ("ldw", C.c_int), ("phase2", C.c_int),
                 ("ln_ksteps", C.c_int), ("ln_out", C.c_void_p),
                 ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int),
-                ("ln_guard", C.c_void_p), ("ln_guard_sigma", C.c_float)]
+                ("ln_guard", C.c_void_p), ("ln_guard_sigma", C.c_float),
+                ("gna_rec", C.c_void_p), ("gna_gamma", C.c_void_p), ("gna_beta", C.c_void_p), ("gna_eps", C.c_float),
+                ("gna_t", C.c_int), ("gna_parts", C.c_int), ("gna_atom", C.c_int), ("gna_rows", C.c_int)]
 
 
 class B2bDesc(C.Structure):

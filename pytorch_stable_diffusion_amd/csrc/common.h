@@ -235,6 +235,13 @@ struct GemmArgs {
   // partial sums, workgroups (kz = 0, tn = 0) also write {mean, rstd} of their rows to ln_out[M][2], and splitk_finalize
   // applies  rstd (sum of folded slabs - mean g) + sum of plain slabs + bias (+ res)
   float* ln_out;
+  // GroupNorm (no SiLU) applied to the A FRAGMENTS in registers (round 4: the attention block's groupnorm -> conv_input pair,
+  // sd/diffusion.py:294-298, without the GroupNorm launch): gna_rec != nullptr -> A is the RAW tensor (fp16), a plain 1x1 GEMM
+  // over one source with K = C0; the workgroup sums the producer's statistics records of its image (GnRec layout: gna_T record
+  // rows, gna_parts, atoms of gna_atom channels) to mean / rstd per group and normalises every fragment between ds_read and MFMA,
+  // y = ((x - mean_hi) - mean_lo) * (rstd gamma) + beta in packed fp16 (the mean as a two-term fp16 sum: x - mean_hi is exact
+  // where it matters, so a large |mean| / sigma costs nothing).  gna_rows: rows per image (a multiple of the tile's BM).
+  const float* gna_rec; const float* gna_gamma; const float* gna_beta; float gna_eps; int gna_T, gna_parts, gna_atom, gna_rows;
   // Guard of the fold: it multiplies the RAW stream's fp16 shadow, so its error grows like |row mean| / sigma x 2^-12 (measured
   // 1.5e-3 at 10 sigma, 3.8e-3 at 30 against 2e-4 unfused).  ln_guard != nullptr: a workgroup that meets a row with
   // mean^2 > ln_guard_thr2 * variance adds 1 to *ln_guard; the caller reads the counter when the loop is over and repeats it
@@ -391,4 +398,5 @@ int sdmi_launch_splitk_finalize(const GemmArgs& a, hipStream_t st);
 bool sdmi_finalize_gacc_ok(const GemmArgs& a, int* T_out = nullptr);
 // record rows per image (GnRec::T) / parts the one-pass epilogue of tile config `cfg` writes
 int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg);
+bool sdmi_gemm_gna_ok(const GemmArgs& a, int cfg);     // this config can normalise its A fragments for this launch (GemmArgs::gna_rec)
 int sdmi_gemm_pick_cfg(const GemmArgs& a);       // the heuristic tile (cfg < 0)

@@ -1077,8 +1077,31 @@ struct Engine {
       TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
       TRY(b2b_qkv(t0, nullptr, w.conv_in, s0, w.in_proj_f, q_scale(w.dh), qk, vt, S, Spad));
     } else {
-      TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
-      { GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs)); }
+      // GroupNorm (no SiLU) -> 1x1 conv_input (sd/diffusion.py:294-298).  SDMI_GN_FRAG=1: with the producer's statistics records at
+      // hand and a plan whose tile was built with the variant, the GEMM normalises its own A fragments (GemmArgs::gna_rec): no
+      // GroupNorm launch, no normalised intermediate.  Parity-green and OFF by default: measured on one MI355X (same box, interleaved)
+      // 259.2 / 259.1 steps/s without against 259.1 / 259.3 with it at 32x32 (5 launches fewer), 258.0 / 255.7 when the 16x16 / 8x8
+      // maps take records too -- the records prologue, the extra LDS reads and the packed-fp16 arithmetic per fragment cost what the
+      // 7 us gn_apply launch gave back, and three fp16 roundings instead of one leave 1.7 x its error on that GEMM
+      // (tests/test_gpu_kernels.py::test_gemm_groupnorm_on_a_fragments).
+      static const bool gna_on = getenv("SDMI_GN_FRAG") && atoi(getenv("SDMI_GN_FRAG")) != 0;
+      bool gna_done = false;
+      if (gna_on && x.gok && x.grec && x.h && !pend && C % (32 * kGnAtom) == 0) {
+        GemmArgs a = base_args(x, nullptr, w.conv_in, x.H, x.W, 1, 0);
+        set_out(a, s0);
+        std::map<ShapeKey, Plan>::iterator it;
+        TRY(plan_of(a, &it));               // (the plan of the plain launch: a shape that has to be timed is timed without the variant)
+        a.gna_rec = x.grec; a.gna_gamma = w.gn.gamma; a.gna_beta = w.gn.beta; a.gna_eps = 1e-6f;
+        a.gna_T = x.gT; a.gna_parts = x.gparts; a.gna_atom = kGnAtom; a.gna_rows = x.H * x.W;
+        if (sdmi_gemm_gna_ok(a, it->second.cfg)) {
+          TRY(gemm(a, &rs));
+          gna_done = true;
+        }
+      }
+      if (!gna_done) {
+        TRY(groupnorm(x, nullptr, w.gn, 1e-6f, 0, &t0));
+        GemmArgs a = base_args(t0, nullptr, w.conv_in, x.H, x.W, 1, 0); set_out(a, s0); TRY(gemm(a, &rs));
+      }
       // self-attention
       if (!rs.ptr) TRY(layernorm(s0, w.ln1, &u));
       GemmArgs a = base_args(rs.ptr ? s0 : u, nullptr, w.in_proj, x.H, x.W, 1, 0);

@@ -373,7 +373,8 @@ __device__ unsigned long long g_clk_pre[2048][10];     // igemm STG 2: producer 
 __device__ unsigned long long g_clk_phase[2048][6];   // {realtime start, end, cycles after setup / K loop / tile in LDS / end}
 #endif
 
-template <class C>
+constexpr int kGnaMaxC = 1280;       // widest K = C of a GroupNorm-on-fragments launch (GemmArgs::gna_rec)
+template <class C, bool GNA = false>
 __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
@@ -599,14 +600,25 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   // MFMA over one staged K-step.  Fragments are double-buffered in registers: the ds_read_b128 of k16
   // sub-step s+1 are issued BEFORE the MFMAs of sub-step s, so the compiler's counted lgkmcnt waits only for
   // the older reads and the LDS latency hides under the matrix pipe (it was exposed 4x per K-step before).
-  auto compute = [&](int buf) {
+  // GroupNorm on the A fragments (GNA kernels, GemmArgs::gna_rec): per channel {mean_hi, mean_lo, rstd gamma, beta} in fp16, written
+  // by gna_prologue below; the lane's eight K columns of sub-step s of K-step kt are kt*64 + 16 s + 8 h .. + 7 for every row
+  __shared__ __attribute__((aligned(16))) f16 s_gna[GNA ? 4 * kGnaMaxC : 8];
+  __shared__ double s_gred[GNA ? 8 : 1][32][2];
+  __shared__ float s_gms[GNA ? 64 : 1];
+  auto compute = [&](int buf, int kt) {
     const char* As = smem + buf * C::STAGE + a_row_off;
     const char* Bs = smem + buf * C::STAGE + C::A_BYTES + b_row_off;
     f16x8 af[2][FM], bf[2][FN];
+    f16x8 gv[2][4];                       // GNA: the four vectors of the sub-step, read one sub-step ahead like the fragments
+    const f16* gsrc = s_gna + (GNA ? kt * 64 + 8 * h : 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(As + i * 32 * 128 + coff[0]);
 #pragma unroll
     for (int j = 0; j < FN; ++j) bf[0][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[0]);
+    if constexpr (GNA) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gv[0][v] = *(const f16x8*)(gsrc + v * kGnaMaxC);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s < 3) {
@@ -614,8 +626,17 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
         for (int i = 0; i < FM; ++i) af[(s + 1) & 1][i] = *(const f16x8*)(As + i * 32 * 128 + coff[s + 1]);
 #pragma unroll
         for (int j = 0; j < FN; ++j) bf[(s + 1) & 1][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s + 1]);
+        if constexpr (GNA) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) gv[(s + 1) & 1][v] = *(const f16x8*)(gsrc + v * kGnaMaxC + 16 * (s + 1));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the next sub-step's reads ahead of this sub-step's MFMAs
+      if constexpr (GNA) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          af[s & 1][i] = __builtin_elementwise_fma((af[s & 1][i] - gv[s & 1][0]) - gv[s & 1][1], gv[s & 1][2], gv[s & 1][3]);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -637,6 +658,83 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
           acc[i][j][e] = s_ln[2 * row + 1] * (acc[i][j][e] - s_ln[2 * row] * gcol);
         }
       }
+  };
+  // GNA prologue: the statistics records of this tile's image -> mean / rstd per group (fp64, as gn_apply_kernel of norm.hip adds
+  // them) -> the four per-channel fp16 vectors.  Three workgroup barriers; every wave of the workgroup calls it exactly once
+  // (the producers after they have primed the ring, so the records' latency hides under the first tiles').
+  auto gna_prologue = [&]() {
+    if constexpr (GNA) {
+      const int Cn = p.C0, cpg = Cn >> 5, apg = cpg / p.gna_atom, natoms = Cn / p.gna_atom;
+      const int img = m0 / p.gna_rows;
+      const int T = p.gna_T, parts = p.gna_parts;
+      // gamma / beta of this thread's channels requested first (they come from HBM: every weight is read once per step)
+      constexpr int NCH = (kGnaMaxC + NT - 1) / NT;
+      float gm[NCH], bt[NCH];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = tid + k * NT;
+        gm[k] = c < Cn ? p.gna_gamma[c] : 0.f;
+        bt[k] = c < Cn ? p.gna_beta[c] : 0.f;
+      }
+      if (tid < 256) {
+        const int g = tid & 31, sl = tid >> 5;          // group, share (8 shares of the group's (atom, record row) pairs)
+        const int npair = apg * T;
+        constexpr int MAXR = 16;
+        f32x4 rv[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+          const int f = sl + 8 * k;
+          rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (f < npair) {
+            const int t = f / apg, a = g * apg + (f - t * apg);
+            const float* rr = p.gna_rec + ((size_t)(img * T + t) * natoms + a) * parts * 2;
+            if (parts == 2) rv[k] = *(const f32x4*)rr;
+            else { const f32x2 u = *(const f32x2*)rr; rv[k][0] = u[0]; rv[k][1] = u[1]; }
+          }
+        }
+        double su = 0.0, sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) { su += (double)rv[k][0] + (double)rv[k][2]; sq += (double)rv[k][1] + (double)rv[k][3]; }
+        for (int f = sl + 8 * MAXR; f < npair; f += 8) {
+          const int t = f / apg, a = g * apg + (f - t * apg);
+          const float* rr = p.gna_rec + ((size_t)(img * T + t) * natoms + a) * parts * 2;
+          su += (double)rr[0]; sq += (double)rr[1];
+          if (parts == 2) { su += (double)rr[2]; sq += (double)rr[3]; }
+        }
+        s_gred[sl][g][0] = su;
+        s_gred[sl][g][1] = sq;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < 32) {
+        double su = 0.0, sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { su += s_gred[k][tid][0]; sq += s_gred[k][tid][1]; }
+        const double cnt = (double)cpg * (double)p.gna_rows;
+        const double mean = su / cnt;
+        double var = sq / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_gms[tid] = (float)mean;
+        s_gms[32 + tid] = rsqrtf((float)var + p.gna_eps);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = tid + k * NT;
+        if (c < Cn) {
+          const int g = c / cpg;
+          const float mean = s_gms[g], rstd = s_gms[32 + g];
+          const f16 mh = (f16)mean;
+          s_gna[c] = mh;
+          s_gna[kGnaMaxC + c] = (f16)(mean - (float)mh);
+          s_gna[2 * kGnaMaxC + c] = (f16)(rstd * gm[k]);
+          s_gna[3 * kGnaMaxC + c] = (f16)bt[k];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
   const int ln_at = (p.ln_stat != nullptr && p.ksplit == 1) ? p.ln_ksteps : 0;   // K-step count after which to rescale (one-pass path; split-K rescales in splitk_finalize)
 #ifdef SDMI_CLK_PROBE
@@ -671,6 +769,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #ifdef SDMI_CLK_PROBE
       const unsigned long long pre1 = __builtin_amdgcn_s_memtime() - clk_t0;
 #endif
+      gna_prologue();
       {
         wait_ring<NS - 2, G>(ni - 1);
       }
@@ -711,6 +810,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       }
 #endif
     } else {
+      gna_prologue();
       __builtin_amdgcn_s_barrier();
       int cur = 0;
 #ifdef SDMI_CLK_PROBE
@@ -724,7 +824,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < KPI; ++j)
           if (t * KPI + j < nk) {
-            compute(cur * KPI + j);
+            compute(cur * KPI + j, kt0 + t * KPI + j);
             if (ln_at && t * KPI + j + 1 == ln_at) rescale_ln();
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -760,7 +860,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       wait_ring<NS - 2, G>(rem);
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < nk) stage(nxt);
-      compute(cur);
+      compute(cur, kt0 + t);
       if (ln_at && t + 1 == ln_at) rescale_ln();
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
@@ -1284,6 +1384,7 @@ struct CfgInfo {
   void (*kern)(GemmArgs);
   void (*hkern)(GemmArgs, int);   // halo-reuse 3x3 kernel (kern == nullptr)
   int ntaph, nw;
+  void (*kern_gna)(GemmArgs);     // the same tile with GroupNorm on the A fragments (GemmArgs::gna_rec), or nullptr
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
@@ -1298,6 +1399,12 @@ struct CfgInfo {
   {"t" #BM "x" #BN "s" #NS "q" #PW, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::NT, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>>, nullptr, 0, 0}
 #define CFG_ENTRY_P2(BM, BN, WM, WN, NS, KPI) \
   {"t" #BM "x" #BN "s" #NS "p" #KPI, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, KPI>::NT, Cfg<BM, BN, WM, WN, NS, 2, KPI>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, KPI>>, nullptr, 0, 0}
+#define CFG_ENTRY_PG(BM, BN, WM, WN, NS) \
+  {"t" #BM "x" #BN "s" #NS "p", BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2>::NT, Cfg<BM, BN, WM, WN, NS, 2>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>>, nullptr, 0, 0, \
+   igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2>, true>}
+#define CFG_ENTRY_QG(BM, BN, WM, WN, NS, PW) \
+  {"t" #BM "x" #BN "s" #NS "q" #PW, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::NT, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>>, nullptr, 0, 0, \
+   igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>, true>}
 const CfgInfo kCfgs[] = {
     CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
     CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
@@ -1311,8 +1418,9 @@ const CfgInfo kCfgs[] = {
     CFG_ENTRY_W(256, 128, 4, 4, 2, "w16"), CFG_ENTRY_W(256, 128, 4, 4, 3, "w16"),
     CFG_ENTRY_W(128, 256, 4, 4, 2, "w16"),
     // wave-specialised (producer/consumer) rings
-    CFG_ENTRY_P(128, 128, 2, 2, 3), CFG_ENTRY_P(128, 128, 2, 2, 4), CFG_ENTRY_P(64, 64, 2, 2, 4),
-    CFG_ENTRY_P(128, 64, 2, 2, 4),  CFG_ENTRY_P(64, 128, 2, 2, 4),
+    // ("G": also built with GroupNorm on the A fragments -- the tiles the attention blocks' conv_input GEMMs are planned with)
+    CFG_ENTRY_P(128, 128, 2, 2, 3), CFG_ENTRY_P(128, 128, 2, 2, 4), CFG_ENTRY_PG(64, 64, 2, 2, 4),
+    CFG_ENTRY_P(128, 64, 2, 2, 4),  CFG_ENTRY_PG(64, 128, 2, 2, 4),
     CFG_ENTRY_P(256, 128, 4, 2, 3), CFG_ENTRY_P(128, 256, 2, 4, 3),
     // specialised, 8 consumer waves (two MFMA waves per SIMD) + 8 producer waves
     CFG_ENTRY_W2(128, 128, 2, 4, 3, "c8"), CFG_ENTRY_W2(128, 128, 4, 2, 3, "c8m"), CFG_ENTRY_W2(128, 128, 2, 4, 4, "c8"),
@@ -1333,7 +1441,7 @@ const CfgInfo kCfgs[] = {
     // n-tiles and no split-K, so at 16x16 / 8x8 (M = 512 / 128) the m-tile count is all the parallelism there is
     CFG_ENTRY_P(32, 128, 1, 4, 4), CFG_ENTRY_P(32, 128, 1, 4, 6), CFG_ENTRY(32, 128, 1, 4, 4),
     // two producer waves per MFMA wave ("q2"): the K = C GEMMs' loop is paced by DMA issue per wave
-    CFG_ENTRY_Q(64, 64, 2, 2, 4, 2), CFG_ENTRY_Q(64, 64, 2, 2, 6, 2), CFG_ENTRY_Q(64, 128, 2, 2, 4, 2), CFG_ENTRY_Q(128, 64, 2, 2, 4, 2),
+    CFG_ENTRY_QG(64, 64, 2, 2, 4, 2), CFG_ENTRY_QG(64, 64, 2, 2, 6, 2), CFG_ENTRY_QG(64, 128, 2, 2, 4, 2), CFG_ENTRY_Q(128, 64, 2, 2, 4, 2),
     CFG_ENTRY_Q(128, 128, 2, 2, 3, 2), CFG_ENTRY_Q(128, 128, 2, 2, 4, 2),
 };
 #define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
@@ -1348,6 +1456,7 @@ constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kMaxDev = 16;
 bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo] = {};   // hipFuncSetAttribute is per device
+bool g_attr_done_gna[kMaxDev][kNumCfgs] = {};
 
 }  // namespace
 
@@ -1391,6 +1500,18 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
     const int hb = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
     if (2 * hb + c.NS * c.BN * 128 + 1024 > 160 * 1024) return false;
   }
+  return true;
+}
+
+// GroupNorm on the A fragments (GemmArgs::gna_rec): a plain 1x1 GEMM over one source, K = C0 <= kGnaMaxC, whole tiles inside one
+// image, a config that was built with the variant
+bool sdmi_gemm_gna_ok(const GemmArgs& a, int cfg) {
+  if (cfg < 0 || cfg >= kNumCfgs) return false;
+  const CfgInfo& c = kCfgs[cfg];
+  if (!c.kern_gna) return false;
+  if (a.ks != 1 || a.stride != 1 || a.ups != 0 || a.C1 != 0 || a.X0 != 0 || a.X1 != 0 || a.K != a.C0 || a.phase2 || a.img_rows || a.ln_stat) return false;
+  if (a.C0 > kGnaMaxC || a.C0 % 320 != 0 || a.gna_atom <= 0 || (a.C0 / 32) % a.gna_atom != 0) return false;
+  if (a.gna_rows <= 0 || a.gna_rows % c.BM != 0 || a.M % a.gna_rows != 0 || a.gna_T <= 0 || (a.gna_parts != 1 && a.gna_parts != 2)) return false;
   return true;
 }
 
@@ -1518,9 +1639,19 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
     SDMI_CHECK_HIP(hipGetLastError());
   } else {
+    if (a.gna_rec) {
+      SDMI_REQUIRE(sdmi_gemm_gna_ok(a, cfg) && a.gna_gamma && a.gna_beta && p.plain, "gemm: config %s cannot apply GroupNorm to its A fragments for this launch", c.name);
+      if (!g_attr_done_gna[dev][cfg]) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.kern_gna, hipFuncAttributeMaxDynamicSharedMemorySize, c.LDS));
+        g_attr_done_gna[dev][cfg] = true;
+      }
+      hipLaunchKernelGGL(c.kern_gna, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
+      SDMI_CHECK_HIP(hipGetLastError());
+    } else {
     if (set_attr((const void*)c.kern, c.LDS) != SDMI_OK) return SDMI_EHIP;
     hipLaunchKernelGGL(c.kern, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS, st, p);
     SDMI_CHECK_HIP(hipGetLastError());
+    }
   }
   if (ksplit_out) *ksplit_out = p.ksplit;
   if (ksteps_per_out) *ksteps_per_out = p.ksteps_per;

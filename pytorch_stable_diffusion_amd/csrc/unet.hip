@@ -591,6 +591,8 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.vec_img_stride = d->vec_img_stride; a.ldw = d->ldw; a.phase2 = d->phase2;
   a.ln_ksteps = d->ln_ksteps; a.ln_out = d->ln_out;
   a.ln_guard = d->ln_guard; a.ln_guard_thr2 = d->ln_guard_sigma * d->ln_guard_sigma;
+  a.gna_rec = d->gna_rec; a.gna_gamma = d->gna_gamma; a.gna_beta = d->gna_beta; a.gna_eps = d->gna_eps;
+  a.gna_T = d->gna_t; a.gna_parts = d->gna_parts; a.gna_atom = d->gna_atom; a.gna_rows = d->gna_rows;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;

@@ -49,7 +49,7 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
           w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None, gstat_rows_img=0, gstat_atom=10, ln_guard=None,
-          ln_guard_sigma=8.0):
+          ln_guard_sigma=8.0, gna=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given).
     gstat_rows_img > 0: the launch also leaves the GroupNorm statistics of its output (sdmi_gemm_desc::gacc); they are returned
     in LAST_STAT = (records [images][T][atoms][parts][2] fp32, T, parts).  ValueError if the config cannot take them."""
@@ -90,6 +90,10 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
     d.act, d.sm_valid, d.img_rows, d.w_img_stride, d.vec_img_stride, d.ldw = act, sm_valid, img_rows, w_img_stride, vec_img_stride, ldw
     if ln_guard is not None:
         d.ln_guard, d.ln_guard_sigma = ln_guard.data_ptr(), ln_guard_sigma
+    if gna is not None:        # (records [images][T][atoms][parts][2], gamma, beta, eps, rows per image): GroupNorm on the A fragments
+        rec, gamma, beta, eps, rows = gna
+        d.gna_rec, d.gna_gamma, d.gna_beta, d.gna_eps = rec.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps
+        d.gna_t, d.gna_parts, d.gna_atom, d.gna_rows = rec.shape[1], rec.shape[3], c0 // rec.shape[2], rows
     if gstat_rows_img:
         d.gacc, d.gacc_atom, d.gacc_rows_img = 16, gstat_atom, gstat_rows_img          # (any non-null pointer for the layout query)
         T, parts = C.c_int(0), C.c_int(0)

@@ -780,6 +780,51 @@ def test_groupnorm_from_producer_statistics(C0, C1, P, in_f32, silu, offset):
     assert d2 < 4e-3, f"differs from the statistics-launch path by {d2}"
 
 
+@pytest.mark.parametrize("C,P,offset,parts", [(640, 1024, 0.0, 2), (1280, 256, 0.0, 1), (640, 1024, 10.0, 2), (1280, 64, 30.0, 1), (320, 4096, -30.0, 2)])
+def test_gemm_groupnorm_on_a_fragments(C, P, offset, parts):
+    """GroupNorm (no SiLU, eps 1e-6) -> 1x1 conv (the attention block's groupnorm -> conv_input, sd/diffusion.py:294-298) as ONE
+    GEMM that normalises its own A fragments from the producer's statistics records (sdmi_gemm_desc::gna_rec): against the fp64
+    result, and against the two-launch path (gn_apply + GEMM) whose error it has to stay close to -- also on rows whose mean sits
+    10 / 30 sigma away from zero (the mean is carried as a two-term fp16 sum)."""
+    B, Nn, atom = 2, 320, 10
+    g = torch.Generator().manual_seed(C + P)
+    x = (torch.randn((B, P, C), generator=g) * (1 + torch.rand((C,), generator=g)) + offset + torch.randn((C,), generator=g)).half()
+    gamma = 1 + 0.2 * torch.randn((C,), generator=g)
+    beta = 0.3 * torch.randn((C,), generator=g)
+    w = (torch.randn((Nn, C), generator=g) / math.sqrt(C)).half()
+    bias = torch.randn((Nn,), generator=g)
+    # the producer's records: moments of the fp16 tensor per (row block of 64, atom); parts = 2 splits them over two slots
+    T = P // 64
+    xb = x.double().view(B, T, 64, C // atom, atom)
+    rec = torch.zeros((B, T, C // atom, parts, 2), dtype=torch.float32)
+    s1, s2 = xb.sum(dim=(2, 4)), (xb * xb).sum(dim=(2, 4))
+    if parts == 2:
+        rec[..., 0, 0], rec[..., 0, 1] = (0.25 * s1).float(), (0.25 * s2).float()
+        rec[..., 1, 0], rec[..., 1, 1] = (0.75 * s1).float(), (0.75 * s2).float()
+    else:
+        rec[..., 0, 0], rec[..., 0, 1] = s1.float(), s2.float()
+    yn = F.group_norm(x.double().permute(0, 2, 1).reshape(B, C, P, 1), 32, gamma.double(), beta.double(), 1e-6)
+    yn = yn.reshape(B, C, P).permute(0, 2, 1)
+    ref = yn.reshape(B * P, C) @ w.double().t() + bias.double()
+    xd, wd, bd = x.to(DEV).view(1, B * P, 1, C), w.to(DEV), bias.to(DEV)
+    y16 = G.groupnorm(x.to(DEV).view(B, P, 1, C), None, gamma.to(DEV), beta.to(DEV), 1e-6, False)          # two-launch path
+    two = G.igemm(y16.view(1, B * P, 1, C), wd, B=1, Hs=B * P, Ws=1, Ho=B * P, Wo=1, bias=bd, out_f32=True)
+    e_two = (two.cpu().double() - ref).abs().max().item()
+    ran = 0
+    for cfg in range(N_.load().sdmi_gemm_num_configs()):
+        try:
+            out = G.igemm(xd, wd, B=1, Hs=B * P, Ws=1, Ho=B * P, Wo=1, bias=bd, out_f32=True, cfg=cfg,
+                          gna=(rec.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, P))
+        except ValueError as exc:
+            assert "cannot apply GroupNorm" in str(exc) or "not applicable" in str(exc), exc
+            continue
+        ran += 1
+        err = (out.cpu().double() - ref).abs().max().item()
+        G.log_metric(test="gemm_gn_fragments", C=C, P=P, offset=offset, cfg=N_.load().sdmi_gemm_config_name(cfg).decode(), max_abs_err=err, two_launch_err=e_two)
+        assert err < max(1.5 * e_two, 6e-3), f"cfg {cfg}: max abs err {err:.3e} (two launches: {e_two:.3e})"
+    assert ran >= 3, "no config ran the variant"
+
+
 def test_back_to_back_gemm_groupnorm_statistics():
     """the feed-forward form of csrc/b2b.hip (the attention block's output at 64x64) leaves the statistics of its output"""
     import ctypes as C
