@@ -206,6 +206,35 @@ def test_loop_20_steps_vs_reference_generate(full_model):
     assert rel < LOOP20_REL_L2, f"final latents rel L2 {rel:.2e} (per-step drift {drift})"
 
 
+@pytest.mark.parametrize("do_cfg,strength", [(False, 1.0), (True, 0.3), (False, 0.5)])
+def test_native_loop_without_guidance_and_with_strength_vs_oracle(full_model, do_cfg, strength):
+    """The corners of sd/pipeline.py:205-237 the goldens do not reach: the loop WITHOUT classifier-free guidance (batch 1, no
+    combine: sd/pipeline.py:118-131,226-233) and a strength-shortened schedule (sd/ddpm.py:90-99: 10 steps, the last
+    int(10 * strength) of them run, t = 0 draws no noise) -- the native fused loop against the oracle's loop on the same latents,
+    contexts and CPU noise stream (16x16 latents keep the fp32 oracle to seconds)."""
+    from oracle import ddpm_ref, unet_ref
+    from pytorch_stable_diffusion_amd.ddpm import DDPMSampler
+    sd = H.full_weights()
+    ctx = H.seeded((2 if do_cfg else 1, 77, 768), 51)
+    lat0 = H.seeded((1, 4, 16, 16), 52)
+    sched = ddpm_ref.RefSchedule()
+    sched.set_inference_timesteps(10)
+    sched.set_strength(strength)
+    gen_ref = torch.Generator(device="cpu").manual_seed(77)
+    ref = ddpm_ref.denoise_loop(lambda x, c, t: unet_ref.diffusion_forward(sd, x, c, t), lat0.clone(), ctx, sched, gen_ref,
+                                cfg_scale=7.5, do_cfg=do_cfg)
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    smp = DDPMSampler(gen)
+    smp.set_inference_timesteps(10)
+    smp.set_strength(strength)
+    assert smp.timesteps.tolist() == sched.timesteps.tolist() and len(smp.timesteps) == int(10 * strength)
+    got = full_model.denoise_native(lat0.to(DEV), ctx.to(DEV), smp, smp.timesteps.tolist(), do_cfg, 7.5).cpu()
+    rel = H.rel_l2(got, ref)
+    G.log_metric(test="loop_corners", do_cfg=do_cfg, strength=strength, steps=len(smp.timesteps), rel_l2=rel)
+    assert rel < LOOP20_REL_L2, f"do_cfg={do_cfg} strength={strength}: rel L2 {rel:.2e}"
+    assert torch.equal(torch.randn(3, generator=gen), torch.randn(3, generator=gen_ref)), "the two loops drew different amounts of noise"
+
+
 def test_attention_blocks_with_separate_layernorm_kernel():
     """The LayerNorm fold is skipped when a producer GEMM is planned split-K; that fallback (layernorm_kernel +
     plain GEMM) must hold the same parity.  The knob is read once per process, hence the child interpreter."""
