@@ -50,7 +50,7 @@ def parse():
                          "chain of launches (UNet batch 2P, per-prompt latents / noise / context; sdmi_unet_denoise_step_batch)")
     ap.add_argument("--no-throughput", action="store_true",
                     help="skip the default throughput legs (with neither --chains nor --batch-prompts given, a 1-GPU run at 64x64 latents "
-                         "also reports 4 prompts as one batched chain and 2 lanes x 4 prompts, beside the single-chain value)")
+                         "also reports 6 prompts as one batched chain and 2 lanes x 6 prompts, beside the single-chain value)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also time BASELINE configs[0] end to end on the host CPU (oracle CLIP x2 + 20 CFG steps + VAE "
@@ -100,7 +100,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     default_legs = args.chains == 1 and args.batch_prompts == 0 and not args.no_throughput and args.gpus == 1 and args.latent == 64
     if default_legs:
-        args.chains, args.batch_prompts = 2, 4       # reported beside `value`; a failure there never touches the contract line
+        args.chains, args.batch_prompts = 2, 6       # reported beside `value`; a failure there never touches the contract line
     if args.batch_prompts > 4:
         os.environ.setdefault("SDMI_ARENA_GB", "24")          # UNet batch > 8: a larger activation arena (csrc/unet.hip), before the handle exists
     # rehearsal knobs (one-GPU box): SDMI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SDMI_BENCH_BACKEND=gloo
