@@ -123,6 +123,13 @@ int64_t sdmi_unet_weight_bytes(const sdmi_unet* u);
  * device the handle lives on.  Every entry point that launches work returns -22 unless that device is current. */
 int sdmi_unet_tuned_shapes(const sdmi_unet* u);
 int sdmi_unet_device(const sdmi_unet* u);
+/* FNV-1a 64 of the loaded libsdmi.so: the key of the per-library plan cache above and of the rocprofv3 counter profiles
+ * bench.py quotes (profiles/<round>_*.json carry the hash of the binary they were taken with). */
+uint64_t sdmi_library_hash(void);
+/* Activation arena of the handle: bytes allocated and the high-water mark of any forward so far.  The arena is sized by the
+ * forward that is about to run (256 KiB per latent pixel and image; SDMI_ARENA_GB, read at create, is a minimum), so a handle
+ * made for single prompts grows by itself when a batched chain (sdmi_unet_denoise_step_batch at P > 4) first comes through. */
+int sdmi_unet_arena(const sdmi_unet* u, int64_t* capacity_out, int64_t* peak_out);
 
 /* ---- VAE decoder (next row after the hot path; reference sd/decoder.py:342-374) ------------------
  * tensors: the 136-entry state dict of VAE_Decoder (keys "0.weight" ... "25.bias",

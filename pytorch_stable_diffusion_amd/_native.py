@@ -82,6 +82,8 @@ _SIGNATURES = {
     "sdmi_unet_weight_bytes": (C.c_int64, [C.c_void_p]),
     "sdmi_unet_tuned_shapes": (C.c_int, [C.c_void_p]),
     "sdmi_unet_device": (C.c_int, [C.c_void_p]),
+    "sdmi_library_hash": (C.c_uint64, []),
+    "sdmi_unet_arena": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sdmi_vae_decoder_create": (C.c_int, [C.POINTER(TensorDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sdmi_vae_destroy": (None, [C.c_void_p]),
     "sdmi_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -146,6 +148,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def library_hash() -> str:
+    """16 hex digits: FNV-1a 64 of the loaded libsdmi.so (the plan cache's key; profiles/*.json are stamped with it)."""
+    return f"{load().sdmi_library_hash():016x}"
 
 
 class SdmiError(RuntimeError):
@@ -460,6 +467,12 @@ class UNetHandle(_DeviceBound):
     @property
     def device_index(self) -> int:
         return self._lib.sdmi_unet_device(self._h)
+
+    def arena(self):
+        """(capacity, high-water mark) of the handle's activation arena in bytes."""
+        cap, peak = C.c_int64(0), C.c_int64(0)
+        check(self._lib.sdmi_unet_arena(self._h, C.byref(cap), C.byref(peak)), "sdmi_unet_arena")
+        return cap.value, peak.value
 
 
 def cfg_ddpm_step(eps, do_cfg, cfg_scale, latents, noise, coef, eps_out=None):

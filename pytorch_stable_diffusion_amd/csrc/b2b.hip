@@ -480,9 +480,17 @@ __global__ __launch_bounds__(Cf::kNT) void b2b_kernel(B2bArgs p) {
                 const f16x2 ones = f16x2{(f16)1.f, (f16)1.f};
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                  const f16x2 x2 = f16x2{o[i][q][2 * h2], o[i][q][2 * h2 + 1]};     // (lanes beyond the 40 owners accumulate junk they never publish)
-                  gq[q][2 * h2] = __builtin_amdgcn_fdot2(x2, ones, gq[q][2 * h2], false);
-                  gq[q][2 * h2 + 1] = __builtin_amdgcn_fdot2(x2, x2, gq[q][2 * h2 + 1], false);
+                  // the moments of WHAT THE GROUPNORM WILL READ (as store_tile, splitk_finalize and the stem take them): the fp32
+                  // values when the stream is fp32 (gn_apply reads x.f), the fp16 ones otherwise
+                  if (p.out_f32) {
+                    const float xa = cv[i][q][2 * h2], xb = cv[i][q][2 * h2 + 1];
+                    gq[q][2 * h2] += xa + xb;
+                    gq[q][2 * h2 + 1] = fmaf(xa, xa, fmaf(xb, xb, gq[q][2 * h2 + 1]));
+                  } else {
+                    const f16x2 x2 = f16x2{o[i][q][2 * h2], o[i][q][2 * h2 + 1]};     // (lanes beyond the 40 owners accumulate junk they never publish)
+                    gq[q][2 * h2] = __builtin_amdgcn_fdot2(x2, ones, gq[q][2 * h2], false);
+                    gq[q][2 * h2 + 1] = __builtin_amdgcn_fdot2(x2, x2, gq[q][2 * h2 + 1], false);
+                  }
                 }
               }
             }

@@ -259,6 +259,7 @@ bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg);
 // a.no_finalize = 1: a split-K launch only writes its slabs; the caller combines them (sdmi_launch_splitk_finalize with
 // those two values filled in, or sdmi_launch_groupnorm with GnArgs::slab)
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out = nullptr, int* ksteps_per_out = nullptr);
+int sdmi_gemm_effective_ksplit(const GemmArgs& a, int cfg, int* ksteps_per_out = nullptr);   // what the launcher's clamps make of a.ksplit
 
 // Back-to-back GEMM of the 320-channel attention blocks (b2b.hip): S = A1 W1^T + b1 + R1, then the next Linear with the
 // LayerNorm of S folded in, in one launch.  All matrices have 320 columns / output rows.

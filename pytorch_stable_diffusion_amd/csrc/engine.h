@@ -83,17 +83,18 @@ constexpr int kGnRecMax = 4096; // records (T x atoms x parts) per image a produ
 
 struct Arena {
   char* base = nullptr;
-  size_t cap = 0, off = 0;
+  size_t cap = 0, off = 0, peak = 0;
   void* alloc(size_t bytes) {
     const size_t a = (off + 255) & ~(size_t)255;
     if (a + bytes > cap) return nullptr;
     off = a + bytes;
+    if (off > peak) peak = off;
     return base + a;
   }
 };
 
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int> ShapeKey;
-struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; long calls = 0; double flops = 0.0; };
+struct Plan { int cfg = -1; int ksplit = 1; float us = 0.f; long calls = 0; double flops = 0.0; bool provisional = false; };
 
 // ---- tuner plan store ---------------------------------------------------------------------------
 // Plans are (cfg NAME, split-K) per GEMM shape key.  Two text tables are read when an engine is created:
@@ -577,13 +578,30 @@ struct Engine {
   }
 
   // ---- activations ---------------------------------------------------------------------------
+  // The arena is sized by the forward that is about to run (unet.hip unet_forward_impl), not by a process-wide knob read once:
+  // a handle made for single prompts grows when a batched chain (pipeline.generate_batch, UNet batch 2P) first comes through
+  // it.  Growing releases the old block first (hipFree waits for the work in flight that still reads it); addresses stay
+  // deterministic per (batch, size) because the forward restarts its bump pointer at 0 either way.
+  int ensure_arena(size_t need) {
+    if (need <= arena.cap) return SDMI_OK;
+    if (arena.base) {
+      for (size_t i = 0; i < owned.size(); ++i)
+        if (owned[i] == (void*)arena.base) { owned.erase(owned.begin() + i); break; }
+      (void)hipFree(arena.base);
+      arena.base = nullptr; arena.cap = 0;
+    }
+    const size_t cap = (need + ((size_t)1 << 30) - 1) >> 30 << 30;          // whole GiB
+    TRY(dmalloc(&arena.base, cap));
+    arena.cap = cap; arena.off = 0;
+    return SDMI_OK;
+  }
   int new_act(int B, int H, int W, int C, bool is_stream, Act* a) {
     a->B = B; a->H = H; a->W = W; a->C = C;
     const size_t n = (size_t)B * H * W * C;
     a->h = (f16*)arena.alloc(n * 2);
     a->f = nullptr;
     if (is_stream && stream_f32) a->f = (float*)arena.alloc(n * 4);
-    if (!a->h || (is_stream && stream_f32 && !a->f)) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
+    if (!a->h || (is_stream && stream_f32 && !a->f)) { sdmi_set_error("activation arena exhausted (%zu MiB; SDMI_ARENA_GB sets a larger minimum)", arena.cap >> 20); return SDMI_ENOMEM; }
     a->grec = nullptr; a->gok = false; a->gT = a->gparts = 0;
     if (is_stream) attach_gacc(a);
     return SDMI_OK;
@@ -598,6 +616,8 @@ struct Engine {
     ShapeKey key(a.M, a.N, a.K, a.ks + 16 * a.pad + 64 * (a.X0 != 0) + 128 * (a.ln_stat != nullptr) + 256 * (a.out_f32 != 0) + 512 * (a.res != nullptr) + 2048 * (a.img_rows != 0),
                  a.stride, a.ups, a.C0, a.C1 + 4096 * (a.lda0 != 0 || a.ldw != 0) + 8192 * a.act, a.Wo, a.outT ? a.nt0 + 1 : 0);
     auto it = plans.find(key);
+    // a lane's heuristic stand-in for a shape its parent had not tuned yet: look the store up again, the parent may have by now
+    if (it != plans.end() && it->second.provisional) { plans.erase(it); it = plans.end(); }
     if (it == plans.end()) {
       Plan pl;
       if (tune) {
@@ -618,11 +638,14 @@ struct Engine {
         }
         // a LANE (sdmi_unet_clone) never times anything: its kernels share the GPU with the other lanes' streams, the cold-L2
         // timings would be distorted and then persisted for every later process.  It runs what its parent tuned (copied at
-        // clone time, or found in the store above once the parent has appended it), else the heuristic tile -- unrecorded
+        // clone time, or found in the store above once the parent has appended it), else the heuristic tile -- unrecorded and
+        // PROVISIONAL: the next call for this shape asks the store again, so the lane converges on its parent's plan
         if (!have && !is_lane) {
           TRY(tune_gemm(a, &pl));
           ++tuned_shapes;
           if (pl.cfg >= 0) ps.append(key, sdmi_gemm_cfg_name(pl.cfg), pl.ksplit, pl.us);
+        } else if (!have) {
+          pl.provisional = true;
         }
       }
       it = plans.emplace(key, pl).first;

@@ -1548,6 +1548,20 @@ size_t sdmi_gemm_slab_bytes(const GemmArgs& a, int /*cfg*/, int ksplit) {
   return ksplit > 1 ? (size_t)ksplit * a.M * a.N * sizeof(float) : 0;
 }
 
+// the split-K factor a launch of `a` with tile config `cfg` really runs with: the requested one clamped to the K-steps there are,
+// slices rounded up to whole channel chunks (9 taps) for the halo kernels, no empty slices
+int sdmi_gemm_effective_ksplit(const GemmArgs& a, int cfg, int* ksteps_per_out) {
+  const int nkt = a.K / 64;
+  int ks = a.ksplit < 1 ? 1 : a.ksplit;
+  if (ks > nkt) ks = nkt;
+  if (ks < 1) ks = 1;
+  int per = (nkt + ks - 1) / ks;
+  if (cfg >= kNumCfgs) per = (per + 8) / 9 * 9;
+  if (per < 1) per = 1;
+  if (ksteps_per_out) *ksteps_per_out = per;
+  return (nkt + per - 1) / per;
+}
+
 int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out, int* ksteps_per_out) {
   SDMI_REQUIRE(a.K % 64 == 0 && a.K > 0, "gemm: K=%d must be a positive multiple of 64", a.K);
   SDMI_REQUIRE(a.N % 8 == 0 && a.N > 0, "gemm: N=%d must be a positive multiple of 8", a.N);
@@ -1596,18 +1610,19 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   if (p.ldx0 <= 0) p.ldx0 = p.X0;
   if (p.ldx1 <= 0) p.ldx1 = p.X1;
   SDMI_REQUIRE(p.lda0 % 8 == 0 && p.lda1 % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8");
-  if (p.ksplit < 1) p.ksplit = 1;
-  if (p.ksplit > nkt) p.ksplit = nkt;
   {
     static const int force = getenv("SDMI_TILE_ORDER") ? atoi(getenv("SDMI_TILE_ORDER")) : -1;   // A/B knob: 0 m-major, 1 n-major
     const double w_bytes = 2.0 * a.N * a.K;
     const double a_bytes = 2.0 * ((double)a.M * a.stride * a.stride / (a.ups ? 4 : 1)) * (a.C0 + a.C1) + 2.0 * a.M * (a.X0 + a.X1);
     p.n_major = force >= 0 ? force : (w_bytes > a_bytes);
   }
-  p.ksteps_per = (nkt + p.ksplit - 1) / p.ksplit;
-  if (halo) p.ksteps_per = (p.ksteps_per + 8) / 9 * 9;  // split at channel-chunk boundaries (9 taps each)
-  p.ksplit = (nkt + p.ksteps_per - 1) / p.ksteps_per;   // no empty splits
+  p.ksplit = sdmi_gemm_effective_ksplit(a, cfg, &p.ksteps_per);
   if (p.ksplit > 1) SDMI_REQUIRE(p.slab != nullptr, "gemm: split-K needs a slab");
+  // The statistics layout (T, parts) was validated above against the REQUESTED split-K factor.  When the clamps lower it to 1
+  // the one-pass epilogue would write its parts = 2 records into a table laid out (and sized) for the combine's parts = 1:
+  // take no statistics instead -- the caller sees the effective factor in *ksplit_out and treats the records as absent
+  // (Engine::gemm: gok = false; sdmi_op_gemm lays its records out for the effective factor up front: unet.hip gacc_layout).
+  if (p.gacc.rec && a.ksplit > 1 && p.ksplit <= 1) p.gacc = GnRec{};
   const int tiles_m = (a.M + c.BM - 1) / c.BM, tiles_n = (a.N + c.BN - 1) / c.BN;
   const int tiles = tiles_m * tiles_n;
   SDMI_REQUIRE((long long)tiles * p.ksplit < (1ll << 22) && (long long)tiles * tiles * p.ksplit < (1ll << 36),

@@ -239,7 +239,8 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   if (hipMemset(u->ln_guard, 0, 256) != hipSuccess) return fail(SDMI_EHIP);
   // activation arena: one bump allocation per forward (deterministic addresses); 6 GiB carry UNet batch <= 8 at 64x64 latents
   // (four prompts of the batched throughput mode) and batch 2 at 96x96; SDMI_ARENA_GB sizes it for more (batch 16: 24)
-  static const size_t arena_gb = getenv("SDMI_ARENA_GB") ? (size_t)atoi(getenv("SDMI_ARENA_GB")) : 6;
+  // (SDMI_ARENA_GB, read per handle: a minimum; a forward that needs more grows it -- Engine::ensure_arena, arena_need below)
+  const size_t arena_gb = getenv("SDMI_ARENA_GB") ? (size_t)atoi(getenv("SDMI_ARENA_GB")) : 6;
   u->arena.cap = u->partial ? ((size_t)1 << 30) : ((arena_gb ? arena_gb : 6) << 30);
   if ((rc = u->dmalloc(&u->arena.base, u->arena.cap)) != SDMI_OK) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) { sdmi_set_error("weight packing failed: %s", hipGetErrorString(hipGetLastError())); return fail(SDMI_EHIP); }
@@ -366,6 +367,11 @@ int sdmi_unet_set_schedule(sdmi_unet* u, const float* temb_dev, int n_steps, voi
   return SDMI_OK;
 }
 
+// Arena bytes one forward of `batch` images of h x w latents may take: the bump allocations of a step add up to ~150 KiB per
+// latent pixel and image with the fp32 residual stream (measured: sdmi_unet_arena after a 512x512 step), 256 KiB leaves room for
+// the odd-size paths (V^T padding, row statistics of every plan)
+static size_t arena_need(int batch, int h, int w) { return (size_t)batch * h * w * ((size_t)256 << 10); }
+
 static int unet_forward_impl(sdmi_unet* u, const float* latents_dev, int latent_batch, const float* temb_dev, int step_idx,
                              float* eps_out_dev, int batch, int h, int w, void* stream, const StepFuse* sf) {
   if (!u || !latents_dev || (!eps_out_dev && !sf)) { sdmi_set_error("forward: null argument"); return SDMI_EINVAL; }
@@ -374,6 +380,7 @@ static int unet_forward_impl(sdmi_unet* u, const float* latents_dev, int latent_
   SDMI_REQUIRE(u->has_stem && u->has_final && u->has_time, "forward: incomplete weights (handle created with SDMI_FLAG_PARTIAL?)");
   TRY(u->enter(stream));
   u->launches = 0;
+  if (!u->partial) TRY(u->ensure_arena(arena_need(batch, h, w)));
   u->arena.off = 0;
   u->launch_log.clear();
   const float* tv;
@@ -535,6 +542,18 @@ int sdmi_unet_ln_guard(sdmi_unet* u, int* hits_out, int reset, int fold_on, void
 int sdmi_unet_last_launch_count(const sdmi_unet* u) { return u ? u->launches : 0; }
 int sdmi_unet_tuned_shapes(const sdmi_unet* u) { return u ? u->tuned_shapes : 0; }
 int sdmi_unet_device(const sdmi_unet* u) { return u ? u->device : -1; }
+// FNV-1a 64 of the loaded library file: the key of the per-library plan cache (engine.h PlanStore) and of the committed counter
+// profiles bench.py quotes (a profile is only valid for the binary it was taken with)
+uint64_t sdmi_library_hash(void) {
+  static const uint64_t h = PlanStore::fnv_file(PlanStore::lib_path());
+  return h;
+}
+int sdmi_unet_arena(const sdmi_unet* u, int64_t* capacity_out, int64_t* peak_out) {
+  if (!u) { sdmi_set_error("sdmi_unet_arena: null handle"); return SDMI_EINVAL; }
+  if (capacity_out) *capacity_out = (int64_t)u->arena.cap;
+  if (peak_out) *peak_out = (int64_t)u->arena.peak;
+  return SDMI_OK;
+}
 int64_t sdmi_unet_weight_bytes(const sdmi_unet* u) { return u ? u->weight_bytes : 0; }
 
 // ---- kernel-level entry points --------------------------------------------------------------
@@ -562,11 +581,15 @@ static int gacc_layout(const sdmi_gemm_desc* d, GemmArgs& a, int* T, int* parts)
   SDMI_REQUIRE(d->gacc_atom >= 4 && d->N % d->gacc_atom == 0 && d->gacc_rows_img > 0, "op_gemm: bad statistics arguments");
   a.gacc.rec = d->gacc; a.gacc.atom = d->gacc_atom; a.gacc.natoms = d->N / d->gacc_atom; a.gacc.rows_img = d->gacc_rows_img;
   a.gacc.mod = d->phase2 ? d->M / 4 : d->M;
-  if (a.ksplit > 1) {
+  const int cfg = d->cfg < 0 ? sdmi_gemm_pick_cfg(a) : d->cfg;
+  SDMI_REQUIRE(cfg >= 0 && cfg < sdmi_gemm_num_cfgs(), "op_gemm: bad cfg %d", cfg);
+  // the layout follows the split-K factor the launcher will really use (it clamps the requested one to the K-steps there are): a
+  // request of 2 on a K = 64 GEMM runs the one-pass epilogue, whose records are parts = 2
+  if (sdmi_gemm_effective_ksplit(a, cfg) > 1) {
     a.gacc.parts = 1;
     SDMI_REQUIRE(sdmi_finalize_gacc_ok(a, &a.gacc.T), "op_gemm: the split-K combine cannot take GroupNorm statistics for this shape");
   } else {
-    const int cfg = d->cfg < 0 ? sdmi_gemm_pick_cfg(a) : d->cfg;
+    a.ksplit = 1;
     a.gacc.parts = 2;
     SDMI_REQUIRE(sdmi_gemm_gacc_ok(a, cfg), "op_gemm: config %s cannot accumulate GroupNorm statistics for this shape", sdmi_gemm_cfg_name(cfg));
     a.gacc.T = sdmi_gemm_gacc_T(a, cfg);

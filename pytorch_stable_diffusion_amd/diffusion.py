@@ -15,6 +15,8 @@ from ._util import normalize_device
 
 
 class Diffusion:
+    _GUARD_EARLY = 3     # steps after which a denoising loop first reads the LayerNorm-fold guard's counter
+
     def __init__(self, stream_f32: bool = True, autotune: bool = True):
         self._manifest = arch.diffusion_manifest()
         self._state: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -25,6 +27,9 @@ class Diffusion:
         self._lanes = []
         self.ln_guard_hits = 0           # rows beyond the LayerNorm-fold guard in the last denoise_native loop
         self.ln_guard_fallback = True    # repeat that loop unfused when there were any
+        self.ln_guard_fallback_ran = False   # ... and whether the last loop was such a repeat
+        self.ln_guard_total_hits = 0     # both summed over the life of the object (run_prompts / bench.py report them)
+        self.ln_guard_fallbacks = 0
         self.stream_f32 = stream_f32
         self.autotune = autotune
 
@@ -97,6 +102,7 @@ class Diffusion:
         ln._ctx_key = None
         ln._lanes = []
         ln.ln_guard_hits, ln.ln_guard_fallback = 0, self.ln_guard_fallback
+        ln.ln_guard_fallback_ran, ln.ln_guard_total_hits, ln.ln_guard_fallbacks = False, 0, 0
         ln._parent = self
         ln._handle = self.handle().clone()
         self._lanes.append(ln)
@@ -169,25 +175,37 @@ class Diffusion:
         rng_state = sampler.generator.get_state()
         h.ln_guard(reset=True)
 
-        def loop():
+        def loop(early_check: bool):
             lat = latents.to(self._device, torch.float32).contiguous().clone()
             for i, t in enumerate(timesteps):
                 noise = sampler.draw_noise(lat.shape, self._device) if t > 0 else None
                 self.step(lat, i, do_cfg, cfg_scale, noise, sampler.step_coefficients(t))
+                # a row beyond the guard shows up in the first steps if it shows up at all (the stream's statistics are set by
+                # the weights, not by the step): one read of the counter after _GUARD_EARLY steps lets a doomed folded loop
+                # stop there instead of paying for all of it before the unfused repeat
+                if early_check and i + 1 == self._GUARD_EARLY and i + 1 < len(timesteps):
+                    early[0] = h.ln_guard(reset=False)
+                    if early[0]:
+                        return None
             return lat
 
-        lat = loop()
+        early = [0]
+        lat = loop(self.ln_guard_fallback)
         # Guard of the LayerNorm fold (include/sdmi.h sdmi_unet_ln_guard): the folded GEMMs multiply the raw stream's fp16
         # shadow, exact enough while a token row's |mean| stays within a few sigma.  The kernels count the rows beyond 8 sigma;
         # when any was met the loop is repeated -- same latents, same noise stream -- through the separate LayerNorm kernel.
-        self.ln_guard_hits = h.ln_guard(reset=True)
+        self.ln_guard_hits = max(h.ln_guard(reset=True), early[0])
+        self.ln_guard_total_hits += self.ln_guard_hits
+        self.ln_guard_fallback_ran = False
         if self.ln_guard_hits and self.ln_guard_fallback:
             sampler.generator.set_state(rng_state)
             h.ln_guard(reset=True, fold_on=False)
             try:
-                lat = loop()
+                lat = loop(False)
             finally:
                 h.ln_guard(reset=True, fold_on=True)
+            self.ln_guard_fallback_ran = True
+            self.ln_guard_fallbacks += 1
         return lat
 
     @torch.no_grad()
@@ -209,23 +227,32 @@ class Diffusion:
         states = [s.generator.get_state() for s in samplers]
         h.ln_guard(reset=True)
 
-        def loop():
+        def loop(early_check: bool):
             x = lat.clone()
             for i, t in enumerate(timesteps):
                 noise = torch.cat([s.draw_noise(one, self._device) for s in samplers]) if t > 0 else None
                 self.step(x, i, do_cfg, cfg_scale, noise, samplers[0].step_coefficients(t))
+                if early_check and i + 1 == self._GUARD_EARLY and i + 1 < len(timesteps):
+                    early[0] = h.ln_guard(reset=False)            # (see denoise_native: one row of one prompt repeats all P)
+                    if early[0]:
+                        return None
             return x
 
-        out = loop()
-        self.ln_guard_hits = h.ln_guard(reset=True)              # guard of the LayerNorm fold: see denoise_native
+        early = [0]
+        out = loop(self.ln_guard_fallback)
+        self.ln_guard_hits = max(h.ln_guard(reset=True), early[0])      # guard of the LayerNorm fold: see denoise_native
+        self.ln_guard_total_hits += self.ln_guard_hits
+        self.ln_guard_fallback_ran = False
         if self.ln_guard_hits and self.ln_guard_fallback:
             for s, st in zip(samplers, states):
                 s.generator.set_state(st)
             h.ln_guard(reset=True, fold_on=False)
             try:
-                out = loop()
+                out = loop(False)
             finally:
                 h.ln_guard(reset=True, fold_on=True)
+            self.ln_guard_fallback_ran = True
+            self.ln_guard_fallbacks += 1
         return out
 
     # ---- reference call convention -------------------------------------------------------------------

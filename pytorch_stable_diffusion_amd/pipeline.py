@@ -133,8 +133,8 @@ def generate_batch(prompts, uncond_prompt="", seeds=None, do_cfg=True, cfg_scale
     draw order (initial latents, then one draw per step with t > 0), its own CLIP contexts, its own VAE decode -- but the UNet
     runs batch 2P through one chain of launches (``Diffusion.denoise_native_batch``), so the weights are streamed once per step
     for all P prompts and the launch-bound low-resolution levels do P times the work per launch.  Same numerics up to the tile
-    plans of the larger GEMMs.  At most 8 prompts (UNet batch 16; more than 4 at 512x512 need SDMI_ARENA_GB=24 set before the model's
-    first use: the activation arena is sized when the handle is made).  Returns a list of (H, W, 3) uint8 images."""
+    plans of the larger GEMMs.  At most 8 prompts (UNet batch 16; the handle's activation arena grows by itself for the batch
+    it is given: csrc/engine.h ensure_arena).  Returns a list of (H, W, 3) uint8 images."""
     with torch.no_grad():
         if height % 64 or width % 64:
             raise ValueError(f"height/width must be multiples of 64, got {height}x{width}")

@@ -239,8 +239,13 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     its seed ``seed_base + i`` and its own noise stream.
 
     Both together: ``streams_per_gpu`` lanes, each carrying groups of ``batch_per_gpu`` prompts -- the batched chains amortise
-    the weight traffic and the launch-bound levels, the lanes fill what latency is left (measured on one MI355X: 2 lanes x 6
-    prompts 512 UNet steps/s in aggregate, one chain 253, one batched chain of 8 460)."""
+    the weight traffic and the launch-bound levels, the lanes fill what latency is left (measured on one MI355X, DESIGN.md 6:
+    2 lanes x 6 prompts 496-523 UNet steps/s in aggregate beside 252-262 for one chain, one batched chain of 8 457-470).  The
+    activation arena of each lane grows by itself for the batch it is given (csrc/engine.h ensure_arena): no environment knob
+    is needed for groups beyond four prompts.
+
+    stats also carries ``ln_guard_hits`` / ``ln_guard_fallbacks``: rows beyond the LayerNorm-fold guard and how many groups
+    repeated their loop unfused because of them (each such group took twice the time)."""
     import threading
     import time
 
@@ -263,6 +268,7 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     lanes = lane_models(models, n_lanes, device=device)
     results: Dict[int, torch.Tensor] = {}
     per_image: Dict[int, float] = {}
+    guard = {"hits": 0, "fallbacks": 0}          # LayerNorm-fold guard of this rank's loops (a fallback doubles a group's latency)
     errors: List[BaseException] = []
 
     def work(lane: int):
@@ -285,6 +291,10 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
                                          models=lanes[lane], seed=seed_base + i, device=device, idle_device=None,
                                          tokenizer=tokenizer, height=height, width=width)]
                 dt = (time.perf_counter() - t1) / len(grp)
+                unet = lanes[lane].get("diffusion")
+                if getattr(unet, "ln_guard_fallback_ran", False):      # this group paid for its loop twice (Diffusion.denoise_native)
+                    guard["fallbacks"] += 1
+                guard["hits"] += int(getattr(unet, "ln_guard_hits", 0) or 0)
                 for (i, _), im in zip(grp, imgs):
                     results[i] = torch.from_numpy(im)
                     per_image[i] = dt
@@ -311,7 +321,8 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
     images = gather_image_lists(mine, len(prompts), (height, width, 3), device=gather_device, group=group)
     stats = {"n_prompts": len(prompts), "world": world, "streams_per_gpu": n_lanes, "batch_per_gpu": batch_per_gpu, "elapsed_s": elapsed,
              "images_per_s": len(prompts) / elapsed if elapsed > 0 else 0.0,
-             "rank0_s_per_image": [per_image[i] for i, _ in todo]}
+             "rank0_s_per_image": [per_image[i] for i, _ in todo],
+             "ln_guard_hits": guard["hits"], "ln_guard_fallbacks": guard["fallbacks"]}
     return images, stats
 
 
@@ -323,10 +334,14 @@ class _null_ctx:
         return False
 
 
-def _main(argv=None) -> int:
+def _main(argv=None, hooks: Optional[Dict[str, object]] = None) -> int:
+    """The launcher's entry point.  ``hooks`` (tests only: the world-8 gloo test drives THIS function on CPU with stub models)
+    may replace what needs a GPU or a checkpoint: "device", "backend", "manifests", "state_dicts" (callable, rank 0 only),
+    "make_models" (state dicts -> models), "generate", "tokenizer", "emit" (callable(record dict, images) on rank 0)."""
     import argparse
     import json
     import os
+    hooks = hooks or {}
 
     ap = argparse.ArgumentParser(prog="python -m pytorch_stable_diffusion_amd.replicas",
                                  description="prompt-parallel generate() over the GPUs of one node (one process per GPU)")
@@ -356,23 +371,29 @@ def _main(argv=None) -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("replicas: needs GPUs (the HIP path has no CPU fallback)")
-    # rendezvous first, on this rank's own device; nothing below re-execs the process
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = hooks.get("backend", args.backend)
+    if "device" in hooks:
+        dev = torch.device(hooks["device"])
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("replicas: needs GPUs (the HIP path has no CPU fallback)")
+        # rendezvous first, on this rank's own device; nothing below re-execs the process
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(backend)
 
     with open(args.prompts_file) as f:
         prompts = [ln.rstrip("\n") for ln in f if ln.strip()]
     if not prompts:
         raise SystemExit("replicas: empty prompts file")
-    if args.stub_tokenizer:
+    if "tokenizer" in hooks:
+        tokenizer = hooks["tokenizer"]
+    elif args.stub_tokenizer:
         from .tokenizer import StubTokenizer
         tokenizer = StubTokenizer()
     else:
@@ -383,26 +404,51 @@ def _main(argv=None) -> int:
 
     sds = None
     if rank == 0:                                   # the checkpoint is read and converted exactly once
-        from . import model_converter, model_loader
-        sds = (model_loader.synthetic_state_dicts() if args.synthetic
-               else model_converter.load_from_standard_weights(args.ckpt, "cpu"))
-    state = broadcast_state_dicts(sds, model_manifests(), dev)
+        if "state_dicts" in hooks:
+            sds = hooks["state_dicts"]()
+        else:
+            from . import model_converter, model_loader
+            sds = (model_loader.synthetic_state_dicts() if args.synthetic
+                   else model_converter.load_from_standard_weights(args.ckpt, "cpu"))
+    manifests = hooks.get("manifests") or model_manifests()
+    # the ONE collective of the path: timed once, between barriers, with what the group itself reports
+    import time
+    if world > 1:
+        dist.barrier()
+    t_b = time.perf_counter()
+    state = broadcast_state_dicts(sds, manifests, dev)
+    bcast_s = max_over_ranks(time.perf_counter() - t_b, device=dev if dev.type == "cuda" else None)
+    bcast_bytes = sum(flat_size(m) for m in manifests.values()) * 4
     del sds
-    from . import model_loader
-    models = model_loader.preload_models_from_state_dicts(state, dev)
+    if "make_models" in hooks:
+        models = hooks["make_models"](state)
+    else:
+        from . import model_loader
+        models = model_loader.preload_models_from_state_dicts(state, dev)
 
+    gdev = dev if dev.type == "cuda" else None
     images, stats = run_prompts(prompts, models, tokenizer, dev, seed_base=args.seed_base, n_inference_steps=args.steps,
-                                cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=dev,
-                                streams_per_gpu=args.streams_per_gpu, batch_per_gpu=args.batch_per_gpu)
+                                cfg_scale=args.cfg_scale, height=args.height, width=args.width, gather_device=gdev,
+                                streams_per_gpu=args.streams_per_gpu, batch_per_gpu=args.batch_per_gpu,
+                                generate=hooks.get("generate"))
+    # the launch checks itself (as bench.py's line does): backend, ranks counted by an all-reduce, every rank's own rate
+    n_mine = len(shard_prompts(prompts, rank, world))
+    facts = group_facts(n_mine / stats["elapsed_s"] if stats["elapsed_s"] > 0 else 0.0, device=gdev)
     if rank == 0:
         if args.out_dir:
             from PIL import Image
             os.makedirs(args.out_dir, exist_ok=True)
             for i, im in enumerate(images):
                 Image.fromarray(im.numpy()).save(os.path.join(args.out_dir, f"image_{i:04d}.png"))
-        print(json.dumps({"metric": "images_per_s", "value": round(stats["images_per_s"], 4), "n_gpus": world,
-                          "n_prompts": len(prompts), "steps": args.steps, "elapsed_s": round(stats["elapsed_s"], 3)}),
-              flush=True)
+        rec = {"metric": "images_per_s", "value": round(stats["images_per_s"], 4), "n_gpus": world,
+               "n_prompts": len(prompts), "steps": args.steps, "elapsed_s": round(stats["elapsed_s"], 3),
+               "dist_backend": facts["backend"], "ranks_seen": facts["ranks_seen"], "per_rank_images_per_s": facts["per_rank"],
+               "weight_broadcast": None if world == 1 else {"bytes": bcast_bytes, "seconds": round(bcast_s, 4),
+                                                             "GB_per_s": round(bcast_bytes / bcast_s / 1e9, 2) if bcast_s > 0 else None},
+               "ln_guard_hits": stats.get("ln_guard_hits", 0), "ln_guard_fallbacks": stats.get("ln_guard_fallbacks", 0)}
+        if "emit" in hooks:
+            hooks["emit"](rec, images)
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

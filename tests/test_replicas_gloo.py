@@ -257,3 +257,64 @@ def test_lanes_of_batched_groups_keep_prompt_order_and_seeds():
     assert by_group[(100, 101)][1] == by_group[(104,)][1] == "sdmi-lane-0" and by_group[(102, 103)][1] == "sdmi-lane-1"
     for a, b in zip(one, two):
         assert torch.equal(a, b)
+
+
+# ---- BASELINE configs[3]'s real shape on CPU: EIGHT ranks through the launcher's own entry point ---------------------------
+def _main_worker(rank, world, port, prompts_file, q):
+    """One rank of `python -m pytorch_stable_diffusion_amd.replicas` as torch.distributed.run would start it (RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_* in the environment), with the hooks that stand in for the GPU: gloo, CPU, stub models."""
+    from tests.stub_tokenizer import StubTokenizer
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank)})
+    seen = []
+
+    def gen(**kw):                                  # records which (prompt, seed) THIS rank generated
+        seen.append((kw["prompt"], kw["seed"]))
+        kw.pop("n_inference_steps", None), kw.pop("height", None), kw.pop("width", None)
+        return _stub_generate(n_inference_steps=3, height=64, width=64, **kw)
+
+    out = {}
+    hooks = {"device": "cpu", "backend": "gloo", "manifests": _STUB_MANIFESTS, "state_dicts": _stub_weights,
+             "make_models": _stub_models, "generate": gen, "tokenizer": StubTokenizer(),
+             "emit": lambda rec, images: out.update(rec=rec, images=[i.numpy() for i in images])}
+    rc = replicas._main(["--prompts-file", prompts_file, "--synthetic", "--stub-tokenizer", "--steps", "3", "--seed-base", "100",
+                         "--height", "64", "--width", "64"], hooks=hooks)
+    q.put((rank, rc, seen, out.get("rec"), out.get("images")))
+
+
+@pytest.mark.parametrize("n_prompts", [8, 11])
+def test_launcher_world8_one_prompt_per_rank(tmp_path, n_prompts):
+    """BASELINE configs[3]: 8 independent prompts over 8 ranks, one each (and 11 prompts: three ranks take a second one).
+    Through replicas._main itself: rank 0 alone makes the weights, ONE broadcast hands them out, prompt i runs on rank i mod 8
+    with seed seed_base + i, rank 0 gathers the images in prompt order, and the record it prints checks the group
+    (ranks_seen == 8, eight per-rank rates, the broadcast timed once)."""
+    from tests.stub_tokenizer import StubTokenizer
+    world = 8
+    prompts = [f"prompt number {i} of the batch" for i in range(n_prompts)]
+    pf = tmp_path / "prompts.txt"
+    pf.write_text("\n".join(prompts) + "\n")
+    models = _stub_models(_stub_weights())
+    want = [_stub_generate(prompt=p, uncond_prompt="", models=models, seed=100 + i, tokenizer=StubTokenizer())
+            for i, p in enumerate(prompts)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_main_worker, args=(r, world, port, str(pf), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rc, seen, rec, images in res:
+        assert rc == 0
+        assert seen == [(prompts[i], 100 + i) for i in range(rank, n_prompts, world)], f"rank {rank} generated {seen}"
+        assert (rec is None) == (rank != 0)                      # only rank 0 emits the record and holds the images
+    rec, images = res[0][3], res[0][4]
+    assert rec["n_gpus"] == 8 and rec["n_prompts"] == n_prompts and rec["dist_backend"] == "gloo"
+    assert rec["ranks_seen"] == 8 and len(rec["per_rank_images_per_s"]) == 8 and all(r > 0 for r in rec["per_rank_images_per_s"])
+    wb = rec["weight_broadcast"]
+    assert wb["bytes"] == 4 * sum(replicas.flat_size(m) for m in _STUB_MANIFESTS.values()) and wb["seconds"] > 0
+    assert len(images) == n_prompts
+    for i, (g, w) in enumerate(zip(images, want)):
+        assert g.shape == (64, 64, 3) and (g == w).all(), f"prompt {i} came back out of order or from the wrong seed"

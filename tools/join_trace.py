@@ -9,6 +9,11 @@
   MFMA busy     : join_trace.py mfma <counter_collection.csv with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE> <launch_log.txt> <out.json> [step_families.json]
                   (with the families file: the busy cycles also over the family's kernel time of the TRACE pass x 2.4 GHz)
 
+  regression    : join_trace.py compare <old step_by_shape.txt> <new step_by_shape.txt> [--tol 0.05] [--allow reasons.txt]
+                  -> per LOGICAL shape (tile config and split-K factor dropped: a re-tuned plan is the same work), the step's
+                     time for it in both profiles; exit code 1 when a shape got more than --tol slower (and more than 1 us)
+                     unless the allow file lists it ("<shape substring> :: <reason>" per line)
+
 A step = the kernels from stem_conv to cfg_ddpm (or final_conv_step, which contains it); log line i is matched to the i-th kernel of the step whose name fits the
 line's kind (fill kernels of hipMemsetAsync and anything else unknown are skipped)."""
 import collections
@@ -212,8 +217,100 @@ def cmd_mfma(csv_path, logp, outp, fam_json=None):
     print(json.dumps(out["families"], indent=1))
 
 
+SHAPE_LINE = re.compile(r"^\s{2}(?!family)(.+?)\s+x\s*(\d+)\s+([0-9.]+) us\s+avg\s+([0-9.]+)")
+
+
+def logical_shape(key):
+    """the work a line stands for, whatever tile plan ran it: 'igemm M= 8192 N= 320 K= 3520 ks=3 s=1 up=0 t128x128s3q2 split 1' and
+    the halo kernel's line for the same conv both become 'conv M=8192 N=320 K=3520 ks=3 s=1 up=0'; the combine of a split-K GEMM
+    is folded into its GEMM (a plan may trade one for the other)"""
+    key = " ".join(key.split())
+    m = re.match(r"(igemm|halo) M= ?(\d+) N= ?(\d+) K= ?(\d+) ks=(\d) s=(\d) up=(\d)", key)
+    if m:
+        return f"conv M={m.group(2)} N={m.group(3)} K={m.group(4)} ks={m.group(5)} s={m.group(6)} up={m.group(7)}"
+    m = re.match(r"finalize M= ?(\d+) N= ?(\d+) K= ?(\d+)", key)
+    if m:
+        return f"finalize M={m.group(1)} N={m.group(2)} K={m.group(3)}"
+    key = re.sub(r" flops=\S+", "", key)
+    key = re.sub(r" split=\d+", "", key)          # gn_fused_slab follows its conv's split-K factor
+    return key
+
+
+def read_shapes(path):
+    out = collections.OrderedDict()
+    for ln in open(path):
+        m = SHAPE_LINE.match(ln)
+        if not m:
+            continue
+        k = logical_shape(m.group(1))
+        e = out.setdefault(k, [0, 0.0])
+        e[0] += int(m.group(2))
+        e[1] += float(m.group(3))
+    # a split-K conv and its combine are one unit of work: fold "finalize M N K" into "conv M N K ..." when exactly one conv has
+    # that (M, N, K); several convs share a combine shape only when their ks / stride differ, then the combine stays its own line
+    for k in [k for k in out if k.startswith("finalize ")]:
+        mnk = k[len("finalize "):]
+        hosts = [c for c in out if c.startswith("conv " + mnk + " ")]
+        if len(hosts) == 1:
+            out[hosts[0]][1] += out[k][1]
+            del out[k]
+    return out
+
+
+def cmd_compare(oldp, newp, tol=0.05, allow=None, floor_us=1.0):
+    old, new = read_shapes(oldp), read_shapes(newp)
+    reasons = []
+    if allow:
+        for ln in open(allow):
+            ln = ln.strip()
+            if ln and not ln.startswith("#") and "::" in ln:
+                pat, why = ln.split("::", 1)
+                reasons.append((pat.strip(), why.strip()))
+    t_old, t_new = sum(v[1] for v in old.values()), sum(v[1] for v in new.values())
+    print(f"step kernel time {t_old:.1f} -> {t_new:.1f} us ({(t_new / t_old - 1) * 100:+.1f} %), {len(old)} -> {len(new)} logical shapes")
+    bad = []
+    rows = []
+    for k in sorted(set(old) | set(new), key=lambda k: -(new.get(k, [0, 0.0])[1] - old.get(k, [0, 0.0])[1])):
+        o, n = old.get(k), new.get(k)
+        if o is None:
+            rows.append(f"  NEW      {k:70s} x{n[0]:3d} {n[1]:8.1f} us")
+            continue
+        if n is None:
+            rows.append(f"  GONE     {k:70s} x{o[0]:3d} {o[1]:8.1f} us")
+            continue
+        d = n[1] - o[1]
+        slow = d > tol * o[1] and d > floor_us and n[1] / max(n[0], 1) > (1 + tol) * o[1] / max(o[0], 1)
+        why = next((w for p, w in reasons if p in k), None) if slow else None
+        tag = "ok"
+        if slow:
+            tag = "ALLOWED" if why else "SLOWER"
+            if not why:
+                bad.append(k)
+        if slow or abs(d) > floor_us:
+            rows.append(f"  {tag:8s} {k:70s} x{o[0]:3d}->{n[0]:3d} {o[1]:8.1f} -> {n[1]:8.1f} us ({d:+7.1f})" + (f"   [{why}]" if why else ""))
+    print("\n".join(rows))
+    # shapes that vanished or appeared change the step only through the total: the gate on them is the step time itself
+    if t_new > (1 + tol) * t_old:
+        bad.append(f"whole step {t_old:.1f} -> {t_new:.1f} us")
+    if bad:
+        print(f"REGRESSION: {len(bad)} shape(s) more than {tol * 100:.0f} % slower per launch than {oldp} with no reason on file:")
+        for k in bad:
+            print("   ", k)
+        return 1
+    print("no unexplained per-shape regression")
+    return 0
+
+
 if __name__ == "__main__":
     c = sys.argv[1]
+    if c == "compare":
+        rest = sys.argv[2:]
+        tol, allow = 0.05, None
+        if "--tol" in rest:
+            i = rest.index("--tol"); tol = float(rest[i + 1]); del rest[i:i + 2]
+        if "--allow" in rest:
+            i = rest.index("--allow"); allow = rest[i + 1]; del rest[i:i + 2]
+        raise SystemExit(cmd_compare(rest[0], rest[1], tol, allow))
     if c == "time":
         rest = sys.argv[2:]
         jout = None
