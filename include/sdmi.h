@@ -30,6 +30,11 @@ extern "C" {
 #define SDMI_FLAG_STREAM_F32 1 /* keep the residual stream in fp32 (fp16 shadow feeds the MFMA operands) */
 #define SDMI_FLAG_PARTIAL 2    /* allow a subset of the 654 tensors (block-level tests) */
 #define SDMI_FLAG_NO_TUNE 4    /* skip the per-shape tile/split-K autotune (heuristic configs) */
+#define SDMI_FLAG_ACCURATE 8   /* ACCURATE mode: every GEMM / conv reads its activation operand in fp32 and multiplies it as a hi + lo
+                                  fp16 pair (two MFMAs per fragment, fp32 accumulate) against the fp16 weights; fp32 tensors between
+                                  the kernels; no LayerNorm fold / back-to-back / halo / folded-cross-attention forms.  What remains
+                                  of the fp16 path's error is the weights' own fp16 rounding: for validation and for weight laws on
+                                  which fp16 activations miss the 1e-3 pixel tolerance.  Several times slower (bench.py accurate_mode) */
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -216,6 +221,10 @@ typedef struct sdmi_gemm_desc {
    * rows per image, gna_parts, atoms of gna_atom channels, gna_rows rows per image), gamma / beta [c0] fp32.  Configs built with the
    * variant only (the "p" / "q2" rings with 64-row tiles); others fail with "cannot apply GroupNorm". */
   const float* gna_rec; const float* gna_gamma; const float* gna_beta; float gna_eps; int gna_t, gna_parts, gna_atom, gna_rows;
+  /* accurate != 0 (the kernels of SDMI_FLAG_ACCURATE): the A operand is read from the fp32 tensors a0f / a1f / x0f / x1f (same
+   * shapes and strides as a0 / a1 / x0 / x1, which are then unused) and multiplied as a hi + lo fp16 pair against the fp16
+   * weights.  cfg < 0 picks the mode's own tile and split-K factor; an explicit cfg must be one built with the variant. */
+  const float* a0f; const float* a1f; const float* x0f; const float* x1f; int accurate;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* record rows per image (T) and parts of the statistics the launch described by d writes to d->gacc (d->gacc != NULL);

@@ -12,7 +12,7 @@ import torch
 from . import build as _build
 
 SDMI_F32, SDMI_F16 = 0, 1
-FLAG_STREAM_F32, FLAG_PARTIAL, FLAG_NO_TUNE = 1, 2, 4
+FLAG_STREAM_F32, FLAG_PARTIAL, FLAG_NO_TUNE, FLAG_ACCURATE = 1, 2, 4, 8
 
 
 class TensorDesc(C.Structure):
@@ -40,7 +40,8 @@ class GemmDesc(C.Structure):
                 ("gacc", C.c_void_p), ("gacc_atom", C.c_int), ("gacc_rows_img", C.c_int),
                 ("ln_guard", C.c_void_p), ("ln_guard_sigma", C.c_float),
                 ("gna_rec", C.c_void_p), ("gna_gamma", C.c_void_p), ("gna_beta", C.c_void_p), ("gna_eps", C.c_float),
-                ("gna_t", C.c_int), ("gna_parts", C.c_int), ("gna_atom", C.c_int), ("gna_rows", C.c_int)]
+                ("gna_t", C.c_int), ("gna_parts", C.c_int), ("gna_atom", C.c_int), ("gna_rows", C.c_int),
+                ("a0f", C.c_void_p), ("a1f", C.c_void_p), ("x0f", C.c_void_p), ("x1f", C.c_void_p), ("accurate", C.c_int)]
 
 
 class B2bDesc(C.Structure):
@@ -132,6 +133,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # Kernel arguments in DEVICE memory: a step is 244 dependent launches whose first instructions read their 100-360 byte
+    # argument blocks; fetched from host-coherent memory every one of them pays a PCIe round trip (measured on one MI355X,
+    # same box and binary: 236.8 steps/s with HIP_FORCE_DEV_KERNARG=0 against 260.2 with 1, profiles/r05_kernarg_placement.json).
+    # The HIP runtime reads the variable when it initialises, i.e. at the first HIP call of the process; an explicit setting wins.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     path = lib_path()
     if build_if_missing and not os.environ.get("SDMI_LIB") and _build.is_stale():
         try:

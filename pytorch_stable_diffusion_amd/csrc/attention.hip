@@ -401,9 +401,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
         const int dd = d * 32 + 8 * g + 4 * h;
         if (dd < D) {
           f16x4 o4;
+          f32x4 of;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = (f16)(oacc[d][4 * g + e] * inv);
+          for (int e = 0; e < 4; ++e) { of[e] = oacc[d][4 * g + e] * inv; o4[e] = (f16)of[e]; }
           *(f16x4*)(op + dd) = o4;
+          if (p.o32) *(f32x4*)(p.o32 + ((size_t)b * p.Sq + qi) * p.ldo + head * D + dd) = of;
         }
       }
   }

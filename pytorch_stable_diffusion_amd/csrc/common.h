@@ -251,7 +251,15 @@ struct GemmArgs {
   // GroupNorm statistics of the output from this launch's epilogue (GnRec above): the one-pass path accumulates them in
   // store_tile, a split-K launch in splitk_finalize.  Needs rows_img % BM == 0 (a tile inside one image), no transposed tail.
   GnRec gacc;
+  // ACCURATE mode (SDMI_FLAG_ACCURATE): accurate = 1 -> the A operand is read from the fp32 tensors a0f / a1f (and x0f / x1f for the
+  // extra 1x1 segment) with the SAME shapes, strides (in elements) and address generator as a0 / a1 / x0 / x1, and enters the
+  // product as a hi + lo fp16 pair (two MFMAs per fragment against the same fp16 weights: gemm.hip igemm_kernel<.., ACC>).  Only
+  // the tile configs built with the variant take it (sdmi_gemm_acc_ok); no halo kernel, no GroupNorm on the fragments.
+  const float* a0f; const float* a1f; const float* x0f; const float* x1f;
+  int accurate;
 };
+bool sdmi_gemm_acc_ok(int cfg);                              // this tile config was built with the wide-operand variant
+int sdmi_gemm_pick_acc_cfg(const GemmArgs& a, int* ksplit);  // the accurate mode's tile and split-K factor for a shape (heuristic; slab_bytes = room for slabs)
 // can the one-pass epilogue of tile config `cfg` accumulate the GroupNorm statistics of this GEMM? (gemm.hip)
 bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg);
 
@@ -304,6 +312,7 @@ struct AttnArgs {
   const f16* k; int ldk;     // [B*Skv_stored][ldk]
   const f16* vt; int ldvt;   // V transposed: [(b*H*d + h*d + dd)][ldvt] (keys contiguous)
   f16* o; int ldo;           // [B*Sq][ldo]
+  float* o32;                // optional fp32 copy of o (same layout; accurate mode: out_proj's wide A operand)
   int B, H, d;               // d in {40, 80, 160} (multiple of 8, <= 160)
   int Sq, Skv;               // Skv = number of valid keys (masking beyond)
   int k_batch_stride;        // rows of k per batch (>= Skv)
@@ -326,6 +335,7 @@ struct GnArgs {
   float eps;
   int silu;
   f16* y;                            // [B*P][C0+C1]
+  float* y32;                        // optional fp32 copy of the output (accurate mode: the next GEMM's wide A operand)
   float* partial;                    // scratch: [B][nchunk][32][2]
   int nchunk;
   // slab != nullptr (single-launch kernel only, C1 = 0): the input is NOT a tensor but the split-K partial sums of the
@@ -367,7 +377,7 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
                           float* gn_rec = nullptr, int gn_rec_T = 0);
 // final conv Cin->4 from NHWC fp16 (already GN+SiLU) to NCHW fp32
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W,
-                           int Cin, int Cout, hipStream_t st);
+                           int Cin, int Cout, hipStream_t st, const float* x32 = nullptr);   // x32: read the input in fp32 (accurate mode)
 // the same conv for prompt i's conditional (b = i) and unconditional (b = P + i) image + CFG combine + DDPM update of the latents
 // (P,4,H,W) in one launch (the eps tensor is never written); coef as sdmi_launch_cfg_ddpm
 int sdmi_launch_final_conv_step(const f16* x, const f16* w, const float* bias, int P, int H, int W, int Cin, int do_cfg, float cfg_scale,

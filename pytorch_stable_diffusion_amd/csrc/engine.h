@@ -187,6 +187,11 @@ struct Engine {
   int flags = 0;
   int device = -1;            // HIP device the handle (weights, arena, plans) lives on
   bool stream_f32 = false, partial = false, tune = true;
+  // ACCURATE mode (SDMI_FLAG_ACCURATE): every tensor that feeds a GEMM also exists in fp32 (Act::f) and enters the product as a
+  // hi + lo fp16 pair (gemm.hip igemm_kernel<.., ACC>); no LayerNorm fold, no back-to-back / halo / folded-cross-attention /
+  // phase-conv forms (each of them multiplies an fp16 activation), heuristic plans (no tuner).  What is left of the fp16 path's
+  // error is the fp16 rounding of the weights and the attention kernel's fp16 q / k / v / p.
+  bool accurate = false;
   bool is_lane = false;       // made by sdmi_unet_clone: borrows its parent's weights, never tunes (plan_of)
   std::vector<void*> owned;   // hipMalloc'd blocks
   int64_t weight_bytes = 0;
@@ -210,6 +215,7 @@ struct Engine {
   // context
   std::vector<std::string> attn_order;
   f16* ctx16 = nullptr;                // [B][80][768]
+  float* ctx32 = nullptr;              // the same in fp32 (accurate mode)
   std::vector<f16*> ctxK, ctxVt;       // per attention block: [B*80][C], [B][C][128]
   // Folded cross-attention.  The context is constant over the denoising loop, so q_proj and out_proj are multiplied INTO
   // the hoisted K and V once per prompt (sd/attention.py:219-256 regrouped):
@@ -331,7 +337,7 @@ struct Engine {
   void free_ctx() {
     for (void* p : ctx_owned) (void)hipFree(p);
     ctx_owned.clear();
-    ctx16 = nullptr;
+    ctx16 = nullptr; ctx32 = nullptr;
     ctxK.clear(); ctxVt.clear();
     xfW1.clear(); xfW2.clear(); xfG.clear(); xfH.clear();
     xf_km = xf_vm = xf_vp = nullptr; xf_kq = nullptr;
@@ -600,8 +606,9 @@ struct Engine {
     const size_t n = (size_t)B * H * W * C;
     a->h = (f16*)arena.alloc(n * 2);
     a->f = nullptr;
-    if (is_stream && stream_f32) a->f = (float*)arena.alloc(n * 4);
-    if (!a->h || (is_stream && stream_f32 && !a->f)) { sdmi_set_error("activation arena exhausted (%zu MiB; SDMI_ARENA_GB sets a larger minimum)", arena.cap >> 20); return SDMI_ENOMEM; }
+    const bool want_f = (is_stream && stream_f32) || accurate;
+    if (want_f) a->f = (float*)arena.alloc(n * 4);
+    if (!a->h || (want_f && !a->f)) { sdmi_set_error("activation arena exhausted (%zu MiB; SDMI_ARENA_GB sets a larger minimum)", arena.cap >> 20); return SDMI_ENOMEM; }
     a->grec = nullptr; a->gok = false; a->gT = a->gparts = 0;
     if (is_stream) attach_gacc(a);
     return SDMI_OK;
@@ -659,27 +666,38 @@ struct Engine {
   // what it writes -- in the one-pass epilogue or in the split-K combine -- if the plan's tile allows it (yact->gok says so)
   int gemm(GemmArgs a, RowStat* rs = nullptr, bool defer = false, Act* yact = nullptr) {
     TRY(flush_pending());
-    std::map<ShapeKey, Plan>::iterator it;
-    TRY(plan_of(a, &it));
-    a.ksplit = it->second.ksplit;
+    std::map<ShapeKey, Plan>::iterator it = plans.end();
+    int plan_cfg = -1;
+    if (accurate) {
+      a.zero = zero; a.slab = slab; a.accurate = 1;
+      if (!a.a0f || (a.C1 && !a.a1f) || (a.X0 && !a.x0f) || (a.X1 && !a.x1f)) { sdmi_set_error("accurate mode: a GEMM operand has no fp32 copy (M=%d N=%d K=%d)", a.M, a.N, a.K); return SDMI_EINVAL; }
+      int ks = 1;
+      plan_cfg = sdmi_gemm_pick_acc_cfg(a, &ks);
+      while (ks > 1 && (size_t)ks * a.M * a.N * 4 > slab_bytes) ks /= 2;
+      a.ksplit = ks;
+    } else {
+      TRY(plan_of(a, &it));
+      a.ksplit = it->second.ksplit;
+      plan_cfg = it->second.cfg;
+    }
     defer = defer && defer_on() && a.ksplit > 1 && !a.outT && !a.act && !a.phase2 && a.cs_hi == 0 && !a.ln_stat && !a.rowstat &&
             a.ldc == a.N && (!a.res || a.ldr == a.N) && a.Ho * a.Wo <= defer_max_px();
     a.no_finalize = 1;                     // the combine is this function's own launch (timed as its own class) or deferred
     if (a.ln_stat && ln_guard) { a.ln_guard = ln_guard; a.ln_guard_thr2 = ln_guard_thr() * ln_guard_thr(); }
     memset(&a.gacc, 0, sizeof(a.gacc));
-    if (yact && yact->grec && !defer && it->second.cfg >= 0) {
+    if (yact && yact->grec && !defer && plan_cfg >= 0) {
       set_gacc(a, *yact);
       bool ok;
       if (a.ksplit > 1) { a.gacc.parts = 1; ok = sdmi_finalize_gacc_ok(a, &a.gacc.T); }
-      else { a.gacc.parts = 2; ok = sdmi_gemm_gacc_ok(a, it->second.cfg); if (ok) a.gacc.T = sdmi_gemm_gacc_T(a, it->second.cfg); }
+      else { a.gacc.parts = 2; ok = sdmi_gemm_gacc_ok(a, plan_cfg); if (ok) a.gacc.T = sdmi_gemm_gacc_T(a, plan_cfg); }
       if (!ok) memset(&a.gacc, 0, sizeof(a.gacc));
     }
     if (rs) {
       const bool no_fold = !ln_fold_on;
       rs->ptr = nullptr;
-      if (!no_fold && a.ksplit == 1 && !a.outT && it->second.cfg >= 0 && it->second.cfg < sdmi_gemm_num_plain_cfgs()) {
+      if (!no_fold && a.ksplit == 1 && !a.outT && plan_cfg >= 0 && plan_cfg < sdmi_gemm_num_plain_cfgs()) {
         int bm, bn;
-        sdmi_gemm_cfg_dims(it->second.cfg, &bm, &bn);
+        sdmi_gemm_cfg_dims(plan_cfg, &bm, &bn);
         const int ntn = (a.N + bn - 1) / bn;
         float* buf = (float*)arena.alloc((size_t)a.M * ntn * 8);
         if (!buf) { sdmi_set_error("activation arena exhausted"); return SDMI_ENOMEM; }
@@ -687,11 +705,13 @@ struct Engine {
         rs->ptr = buf; rs->ntn = ntn;
       }
     }
-    it->second.calls += 1;
-    it->second.flops = 2.0 * a.M * a.N * a.K;
+    if (it != plans.end()) {
+      it->second.calls += 1;
+      it->second.flops = 2.0 * a.M * a.N * a.K;
+    }
     int ks_eff = 1, kper = 0;
     prof_begin(0, 2.0 * a.M * a.N * a.K);
-    TRY(sdmi_launch_gemm(a, it->second.cfg, st, &ks_eff, &kper));
+    TRY(sdmi_launch_gemm(a, plan_cfg, st, &ks_eff, &kper));
     prof_end();
     const bool deferred = defer && ks_eff > 1;
     // (the launcher may lower the split-K factor: statistics taken by the combine need ks_eff > 1, by the epilogue == 1)
@@ -713,7 +733,7 @@ struct Engine {
     const int nl = (ks_eff > 1 && !deferred) ? 2 : 1;
     launches += nl;
     if (logging) {
-      const int cfg = it->second.cfg;
+      const int cfg = plan_cfg;
       const bool halo = cfg >= sdmi_gemm_num_plain_cfgs();
       log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
                  a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.ksplit, 2.0 * a.M * a.N * a.K,
@@ -799,8 +819,8 @@ struct Engine {
   static GemmArgs base_args(const Act& x, const Act* x1, const ConvW& w, int Ho, int Wo, int stride, int ups) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.a0 = x.h; a.C0 = x.C;
-    if (x1) { a.a1 = x1->h; a.C1 = x1->C; }
+    a.a0 = x.h; a.a0f = x.f; a.C0 = x.C;
+    if (x1) { a.a1 = x1->h; a.a1f = x1->f; a.C1 = x1->C; }
     a.Hs = x.H; a.Ws = x.W; a.Ho = Ho; a.Wo = Wo;
     a.ups = ups; a.stride = stride; a.ks = w.ks; a.pad = w.ks == 3 ? 1 : 0;
     a.M = x.B * Ho * Wo; a.N = w.O; a.K = w.ks * w.ks * (a.C0 + a.C1);
@@ -830,7 +850,7 @@ struct Engine {
     g.in_f32 = f32; g.C0 = x.C; g.C1 = x1 ? x1->C : 0;
     g.B = x.B; g.P = x.H * x.W;
     g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
-    g.y = y->h; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
+    g.y = y->h; g.y32 = accurate ? y->f : nullptr; g.partial = gn_partial; g.nchunk = sdmi_gn_nchunk(g.P);
     // x is the output of a split-K conv that has not been combined yet: combine + normalise in one launch
     // statistics already taken by the producers' epilogues: one normalising pass (maps the single-launch kernel handles in
     // 64 workgroups keep it below gacc_min_px: attach_gacc)
@@ -884,7 +904,7 @@ struct Engine {
     memset(&l, 0, sizeof(l));
     l.x = x.f ? (const void*)x.f : (const void*)x.h;
     l.in_f32 = x.f != nullptr;
-    l.M = x.M(); l.C = x.C; l.gamma = w.gamma; l.beta = w.beta; l.eps = 1e-5f; l.y = y->h;
+    l.M = x.M(); l.C = x.C; l.gamma = w.gamma; l.beta = w.beta; l.eps = 1e-5f; l.y = y->h; l.y32 = accurate ? y->f : nullptr;
     prof_begin(2, 0.0);
     TRY(sdmi_launch_layernorm(l, st));
     prof_end();
@@ -908,6 +928,7 @@ struct Engine {
       TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
       GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
       a.bias = bias1; a.out = h.h; a.ldc = h.C;
+      if (accurate) set_out(a, h);             // groupnorm_merged reads the fp32 values
       pend_keep16 = false;                     // h has one reader: groupnorm_merged
       attach_gacc(&h);
       TRY(gemm(a, nullptr, /*defer=*/true, &h));
@@ -923,8 +944,8 @@ struct Engine {
     TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
     GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
     if (r.has_skip && r.w2s) {                 // the 1x1 skip conv as an extra K-range of conv_merged (sd/diffusion.py:143,209)
-      a.x0 = x.h; a.X0 = x.C;
-      if (x1) { a.x1 = x1->h; a.X1 = x1->C; }
+      a.x0 = x.h; a.x0f = x.f; a.X0 = x.C;
+      if (x1) { a.x1 = x1->h; a.x1f = x1->f; a.X1 = x1->C; }
       a.K += a.X0 + a.X1;
       a.w = r.w2s; a.bias = r.bias2s;
     } else if (r.has_skip) {
@@ -939,12 +960,12 @@ struct Engine {
   }
 
   int attention(const f16* q, int ldq, const f16* k, int ldk, int kbs, const f16* vt, int ldvt, f16* o, int ldo, int B,
-                int d, int Sq, int Skv) {
+                int d, int Sq, int Skv, float* o32 = nullptr) {
     TRY(flush_pending());
     AttnArgs t;
     memset(&t, 0, sizeof(t));
     t.q = q; t.ldq = ldq; t.k = k; t.ldk = ldk; t.k_batch_stride = kbs; t.vt = vt; t.ldvt = ldvt;
-    t.o = o; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero; t.ones = zero + 1024;
+    t.o = o; t.o32 = o32; t.ldo = ldo; t.B = B; t.H = kHeads; t.d = d; t.Sq = Sq; t.Skv = Skv; t.zero = zero; t.ones = zero + 1024;
     t.scale = 1.f / sqrtf((float)d); t.prescaled = 1;       // callers fold scale*log2(e) into the Q projection (q_scale)
     prof_begin(1, 4.0 * B * kHeads * (double)Sq * Skv * d);
     TRY(sdmi_launch_attention(t, st));
@@ -1074,7 +1095,7 @@ struct Engine {
     // nearly empty round makes the fused form slower than the GEMM pairs (same box: 8.17 vs 8.11 ms/step)
     // (beyond 16384 rows -- the batched multi-prompt mode -- only whole rounds of 64-row workgroups: SDMI_B2B_FULLROUNDS=0 to A/B)
     static const bool b2b_rounds = !(getenv("SDMI_B2B_FULLROUNDS") && atoi(getenv("SDMI_B2B_FULLROUNDS")) == 0);
-    const bool use_b2b = b2b_on && !no_fold && C == 320 && (B * S) % 32 == 0 &&
+    const bool use_b2b = b2b_on && !no_fold && !accurate && C == 320 && (B * S) % 32 == 0 &&
                          (B * S <= 16384 || (b2b_rounds && (B * S) % (64 * 256) == 0 && S % 64 == 0));
     TRY(new_act(B, x.H, x.W, 2 * C, false, &qk));
     f16* vt = (f16*)arena.alloc((size_t)B * C * Spad * 2);
@@ -1135,7 +1156,7 @@ struct Engine {
       TRY(gemm(a));
     }
     TRY(new_act(B, x.H, x.W, C, false, &ao));
-    TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S));
+    TRY(attention(qk.h, 2 * C, qk.h + C, 2 * C, S, vt, Spad, ao.h, C, B, w.dh, S, S, accurate ? ao.f : nullptr));
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s1));
     bool q_done = false;
     if (use_b2b) {
@@ -1147,7 +1168,7 @@ struct Engine {
     }
     // cross-attention (K/V hoisted in set_context)
     static const bool xfold_on = !(getenv("SDMI_XATTN_FOLD") && atoi(getenv("SDMI_XATTN_FOLD")) == 0);
-    const bool xfold = !q_done && xfold_on && rs.ptr && S % 64 == 0 && S <= 1024 && (int)xfW1.size() > w.ctx_idx && xfW1[w.ctx_idx] != nullptr;
+    const bool xfold = !q_done && xfold_on && !accurate && rs.ptr && S % 64 == 0 && S <= 1024 && (int)xfW1.size() > w.ctx_idx && xfW1[w.ctx_idx] != nullptr;
     TRY(new_act(B, x.H, x.W, C, inner_f32, &s2));
     if (xfold) {
       // two GEMMs with per-image weights (see xfW1 / xfW2): probabilities, then values x out_proj + residual
@@ -1180,7 +1201,7 @@ struct Engine {
         a.cscale = q_scale(w.dh); a.cs_hi = C;
         TRY(gemm(a));
       }
-      TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens));
+      TRY(attention(q2.h, C, ctxK[w.ctx_idx], C, kCtxPad, ctxVt[w.ctx_idx], kCtxVtLd, ao.h, C, B, w.dh, S, ctx_tokens, accurate ? ao.f : nullptr));
       if (use_b2b) {
         // s2 = out_proj 2 + s1 never leaves the workgroup: its only reader is the feed-forward
         TRY(new_act(B, x.H, x.W, C, true, y));
@@ -1219,7 +1240,7 @@ struct Engine {
     // weight-bound).  SDMI_UPS_PHASE=0: never; SDMI_UPS_PHASE_MINROWS moves the threshold.
     static const bool phase_on = !(getenv("SDMI_UPS_PHASE") && atoi(getenv("SDMI_UPS_PHASE")) == 0);
     static const int phase_min = getenv("SDMI_UPS_PHASE_MINROWS") ? atoi(getenv("SDMI_UPS_PHASE_MINROWS")) : 512;
-    if (phase_on && ups == 1 && stride == 1 && pad == 1 && w.w4 && x.M() >= phase_min && x.M() % 64 == 0) {
+    if (phase_on && !accurate && ups == 1 && stride == 1 && pad == 1 && w.w4 && x.M() >= phase_min && x.M() % 64 == 0) {
       ConvW wp = w;
       wp.w = w.w4; wp.ks = 2;
       GemmArgs a = base_args(x, nullptr, wp, x.H, x.W, 1, 0);

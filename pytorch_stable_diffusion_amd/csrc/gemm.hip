@@ -17,6 +17,7 @@
 //     fp16 and/or fp32 output, optional transposed tail (V^T for the attention kernel);
 //   * split-K over gridDim.y writes fp32 slabs combined by splitk_finalize (small-M layers).
 #include "common.h"
+#include <type_traits>
 
 #ifndef SDMI_GACC_ABLATE
 #define SDMI_GACC_ABLATE 0      // diagnostic builds: 1 = no flush at all, 2 = flush without the record stores, 4 = no per-item accumulation
@@ -374,8 +375,16 @@ __device__ unsigned long long g_clk_phase[2048][6];   // {realtime start, end, c
 #endif
 
 constexpr int kGnaMaxC = 1280;       // widest K = C of a GroupNorm-on-fragments launch (GemmArgs::gna_rec)
-template <class C, bool GNA = false>
+// ACC (the ACCURATE mode, SDMI_FLAG_ACCURATE; the plain STG 0 ring only): the A operand comes from the fp32 tensors (GemmArgs::a0f
+// ...) and is split on its way into LDS into a hi + lo fp16 pair, a = hi + lo with hi = fp16(a), lo = fp16(a - hi); every
+// fragment is multiplied twice against the same W fragment, acc += hi W + lo W.  The activation then enters the product with
+// ~22 significant bits instead of 11 (what is left is the fp16 rounding of the WEIGHTS, the measured 4.7e-4 floor of
+// tests/golden/stress_floor.json against 1.4e-3 for fp16 activations).  Twice the MFMA work and the A tile staged through
+// registers (global_load fp32 -> split -> ds_write, in the lane-linear image the LDS-DMA would have written): a validation /
+// high-accuracy path whose cost bench.py reports as `accurate_mode`, not the default.
+template <class C, bool GNA = false, bool ACC = false>
 __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
+  static_assert(!ACC || (C::STG == 0 && !GNA && C::NT < 1024), "the wide-operand variant is built on the plain ring");
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -472,7 +481,13 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   // boundaries (every C_src/64 steps) and a K-step costs two 64-bit adds per staged row.
   int a_ihb[RA], a_iwb[RA], a_pix0[RA], a_gch[RA];
   bool a_ok[RA];
-  const f16* a_ptr[RA];
+  typedef typename std::conditional<ACC, float, f16>::type AT;      // element type of the A sources
+  // (the segment walk below selects between MEMBERS of the argument struct, never between local copies of them: a lambda captures
+  // locals by address, the compiler turns select(load a, load b) into load(select(&a, &b)) inside it, and locals whose addresses
+  // feed a select stay in scratch memory -- seen as 900 B of scratch per lane in a first form of the wide-operand variant; a
+  // run-time offset into the kernarg segment is just a scalar load)
+  const AT* const src_zero = (const AT*)(const void*)p.zero;       // >= 2 KB of zero bytes: 8 fp32 at chunk offsets up to 56 fit
+  const AT* a_ptr[RA];
   int a_inc[RA];
   const bool plain = C::NT < 1024 && p.plain;      // (the 16-wave kernels have no registers to spare for a second path)
 #pragma unroll
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       // plain GEMM (every linear / 1x1 conv over one source: 122 of the launches of a step): output row m IS source row m and K is
       // ONE segment, so neither the im2col decomposition (four integer divisions per staged row) nor the segment walk exists --
       // the prologue of these launches was ~2 k cycles of address arithmetic before the first tile was requested
-      a_ptr[i] = a_ok[i] ? p.a0 + ((size_t)mm * p.lda0 + (size_t)kt0 * 64 + a_gch[i]) : p.zero + a_gch[i];
+      a_ptr[i] = a_ok[i] ? (ACC ? (const AT*)(const void*)p.a0f : (const AT*)(const void*)p.a0) + ((size_t)mm * p.lda0 + (size_t)kt0 * 64 + a_gch[i]) : src_zero + a_gch[i];
       a_inc[i] = a_ok[i] ? 64 : 0;
       a_ihb[i] = 0; a_iwb[i] = 0; a_pix0[i] = mm;
     } else if (p.ks == 1 && p.stride == 1 && p.ups == 0) {
@@ -544,7 +559,9 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     const int kw = extra ? p.pad : ((p.ks == 3) ? tap - (tap / 3) * 3 : (p.ks == 2 ? tap & 1 : 0));
     const int Ca = extra ? p.X0 : p.C0, Cb = extra ? p.X1 : p.C1;
     const bool second = seg_c >= Ca;
-    const f16* base = extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0);
+    const AT* base;
+    if constexpr (ACC) base = (const AT*)(const void*)(extra ? (second ? p.x1f : p.x0f) : (second ? p.a1f : p.a0f));
+    else base = (const AT*)(const void*)(extra ? (second ? p.x1 : p.x0) : (second ? p.a1 : p.a0));
     const int cs = second ? Cb : Ca;
     const int ld = extra ? (second ? p.ldx1 : p.ldx0) : (second ? p.lda1 : p.lda0);
     const int cc = second ? seg_c - Ca : seg_c;
@@ -554,8 +571,8 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       const int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
       const bool v = a_ok[i] && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
       const int pix = a_pix0[i] + (extra ? ih * p.Ws + iw : (ih >> p.ups) * p.Ws + (iw >> p.ups));
-      const f16* gr = base + ((size_t)pix * ld + cc + a_gch[i]);
-      const f16* gz = p.zero + a_gch[i];
+      const AT* gr = base + ((size_t)pix * ld + cc + a_gch[i]);
+      const AT* gz = src_zero + a_gch[i];
       a_ptr[i] = v ? gr : gz;
       a_inc[i] = v ? 64 : 0;
     }
@@ -563,10 +580,41 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     if (seg_c >= Ca + Cb) { seg_c = 0; ++tap; }
   };
 
+  constexpr int STAGE = C::STAGE + (ACC ? C::A_BYTES : 0);      // ACC: [A hi | A lo | W] per stage
+  constexpr int B_OFF = C::A_BYTES * (ACC ? 2 : 1);
   auto stage = [&](int buf) {
-    char* sa = smem + buf * C::STAGE;
-    char* sb = sa + C::A_BYTES;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + B_OFF;
     if (seg_left == 0) open_segment();
+    if constexpr (ACC) {
+      // through registers: 8 fp32 per lane and row chunk -> hi | lo fp16 -> the two A images, at the LDS position the 16-byte
+      // LDS-DMA of the same lane would have written (wave base + lane * 16), so the fragment reads below do not change
+      f32x4 v0[RA], v1[RA];
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        typedef const __attribute__((address_space(1))) f32x4* gvec_t;      // global, not flat: the tensors live in device memory
+        v0[i] = *(gvec_t)(const void*)a_ptr[i];
+        v1[i] = *(gvec_t)(const void*)(a_ptr[i] + 4);
+        a_ptr[i] += a_inc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        glds16(b_ptr[i], sb + (i * SW + sw) * 1024);
+        b_ptr[i] += b_inc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = e < 4 ? v0[i][e] : v1[i][e - 4];
+          hi[e] = (f16)x;
+          lo[e] = (f16)(x - (float)hi[e]);
+        }
+        *(f16x8*)(sa + (i * SW + sw) * 1024 + lane * 16) = hi;
+        *(f16x8*)(sa + C::A_BYTES + (i * SW + sw) * 1024 + lane * 16) = lo;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       glds16(a_ptr[i], sa + (i * SW + sw) * 1024);
@@ -576,6 +624,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     for (int i = 0; i < RB; ++i) {
       glds16(b_ptr[i], sb + (i * SW + sw) * 1024);
       b_ptr[i] += b_inc[i];
+    }
     }
     --seg_left;
   };
@@ -606,13 +655,18 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   __shared__ double s_gred[GNA ? 8 : 1][32][2];
   __shared__ float s_gms[GNA ? 64 : 1];
   auto compute = [&](int buf, int kt) {
-    const char* As = smem + buf * C::STAGE + a_row_off;
-    const char* Bs = smem + buf * C::STAGE + C::A_BYTES + b_row_off;
+    const char* As = smem + buf * STAGE + a_row_off;
+    const char* Bs = smem + buf * STAGE + B_OFF + b_row_off;
     f16x8 af[2][FM], bf[2][FN];
+    f16x8 al[2][ACC ? FM : 1];            // ACC: the lo halves of the A fragments
     f16x8 gv[2][4];                       // GNA: the four vectors of the sub-step, read one sub-step ahead like the fragments
     const f16* gsrc = s_gna + (GNA ? kt * 64 + 8 * h : 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(As + i * 32 * 128 + coff[0]);
+    if constexpr (ACC) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) al[0][i] = *(const f16x8*)(As + C::A_BYTES + i * 32 * 128 + coff[0]);
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) bf[0][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[0]);
     if constexpr (GNA) {
@@ -624,6 +678,10 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
       if (s < 3) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[(s + 1) & 1][i] = *(const f16x8*)(As + i * 32 * 128 + coff[s + 1]);
+        if constexpr (ACC) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) al[(s + 1) & 1][i] = *(const f16x8*)(As + C::A_BYTES + i * 32 * 128 + coff[s + 1]);
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) bf[(s + 1) & 1][j] = *(const f16x8*)(Bs + j * 32 * 128 + coff[s + 1]);
         if constexpr (GNA) {
@@ -636,6 +694,13 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
           af[s & 1][i] = __builtin_elementwise_fma((af[s & 1][i] - gv[s & 1][0]) - gv[s & 1][1], gv[s & 1][2], gv[s & 1][3]);
+      }
+      if constexpr (ACC) {                 // the small terms first: lo W, then hi W on top
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -849,7 +914,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
   //   barrier (also closes the WAR window on the buffer read in iteration t-1), issue step t+NS-1
   //   into that buffer, then MFMA over buffer t % NS.
   constexpr int NS = C::NS;
-  constexpr int G = RA + RB;              // LDS-DMA instructions per wave per stage
+  constexpr int G = ACC ? RB : RA + RB;   // LDS-DMA instructions per wave per stage (ACC: the A rows come through registers, waited for in stage())
   {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -858,6 +923,7 @@ __global__ __launch_bounds__(C::NT) void igemm_kernel(GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
       const int rem = nk - 1 - t;           // groups issued after step t
       wait_ring<NS - 2, G>(rem);
+      if constexpr (ACC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's ds_writes of the A images (a raw barrier waits for no counter)
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < nk) stage(nxt);
       compute(cur, kt0 + t);
@@ -1385,10 +1451,18 @@ struct CfgInfo {
   void (*hkern)(GemmArgs, int);   // halo-reuse 3x3 kernel (kern == nullptr)
   int ntaph, nw;
   void (*kern_gna)(GemmArgs);     // the same tile with GroupNorm on the A fragments (GemmArgs::gna_rec), or nullptr
+  void (*kern_acc)(GemmArgs);     // the same tile with the fp32 A operand as a hi + lo fp16 pair (GemmArgs::accurate), or nullptr
+  int LDS_acc;
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
   {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>, nullptr, 0, 0}
+#define ACC_LDS(BM, BN, WM, WN, NS) \
+  ((NS * (Cfg<BM, BN, WM, WN, NS>::STAGE + Cfg<BM, BN, WM, WN, NS>::A_BYTES)) > Cfg<BM, BN, WM, WN, NS>::CS_BYTES ? \
+   (NS * (Cfg<BM, BN, WM, WN, NS>::STAGE + Cfg<BM, BN, WM, WN, NS>::A_BYTES)) : Cfg<BM, BN, WM, WN, NS>::CS_BYTES)
+#define CFG_ENTRY_A(BM, BN, WM, WN, NS) \
+  {"t" #BM "x" #BN "s" #NS, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>, nullptr, 0, 0, \
+   nullptr, igemm_kernel<Cfg<BM, BN, WM, WN, NS>, false, true>, ACC_LDS(BM, BN, WM, WN, NS)}
 #define CFG_ENTRY_W(BM, BN, WM, WN, NS, TAG) \
   {"t" #BM "x" #BN "s" #NS TAG, BM, BN, NS, Cfg<BM, BN, WM, WN, NS>::NT, Cfg<BM, BN, WM, WN, NS>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS>>, nullptr, 0, 0}
 #define CFG_ENTRY_P(BM, BN, WM, WN, NS) \
@@ -1406,10 +1480,11 @@ struct CfgInfo {
   {"t" #BM "x" #BN "s" #NS "q" #PW, BM, BN, NS, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::NT, Cfg<BM, BN, WM, WN, NS, 2, 1, PW>::LDS, igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>>, nullptr, 0, 0, \
    igemm_kernel<Cfg<BM, BN, WM, WN, NS, 2, 1, PW>, true>}
 const CfgInfo kCfgs[] = {
-    CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
+    // ("A": also built with the wide A operand of the accurate mode, GemmArgs::accurate)
+    CFG_ENTRY(128, 128, 2, 2, 2), CFG_ENTRY_A(128, 128, 2, 2, 3), CFG_ENTRY(128, 128, 2, 2, 4),
     CFG_ENTRY(128, 64, 2, 2, 2),  CFG_ENTRY(128, 64, 2, 2, 4),
-    CFG_ENTRY(64, 128, 2, 2, 2),  CFG_ENTRY(64, 128, 2, 2, 4),
-    CFG_ENTRY(64, 64, 2, 2, 2),   CFG_ENTRY(64, 64, 2, 2, 3),  CFG_ENTRY(64, 64, 2, 2, 4),
+    CFG_ENTRY(64, 128, 2, 2, 2),  CFG_ENTRY_A(64, 128, 2, 2, 4),
+    CFG_ENTRY(64, 64, 2, 2, 2),   CFG_ENTRY(64, 64, 2, 2, 3),  CFG_ENTRY_A(64, 64, 2, 2, 4),
     CFG_ENTRY(256, 128, 4, 2, 2), CFG_ENTRY(256, 128, 4, 2, 3),
     CFG_ENTRY(128, 256, 2, 4, 2), CFG_ENTRY(128, 256, 2, 4, 3),
     // 8/16-wave variants: two waves per SIMD so DMA issue / LDS latency of one hides under the other's MFMAs
@@ -1457,6 +1532,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kMaxDev = 16;
 bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo] = {};   // hipFuncSetAttribute is per device
 bool g_attr_done_gna[kMaxDev][kNumCfgs] = {};
+bool g_attr_done_acc[kMaxDev][kNumCfgs] = {};
 
 }  // namespace
 
@@ -1533,6 +1609,39 @@ int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg) {
   return (a.M / a.gacc.mod) * (a.gacc.rows_img / c.BM);
 }
 
+bool sdmi_gemm_acc_ok(int cfg) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].kern_acc != nullptr; }
+
+// Tile and split-K factor of an accurate-mode launch.  No tuner here (the mode is for validation, its plans must not depend on
+// timings): the largest of the three wide-operand tiles that still gives the chip a round of workgroups, K split to fill the
+// rest where the epilogue allows it.
+int sdmi_gemm_pick_acc_cfg(const GemmArgs& a, int* ksplit) {
+  int best = -1;
+  auto find = [&](int bm, int bn) { for (int c = 0; c < kNumCfgs; ++c) if (kCfgs[c].kern_acc && kCfgs[c].BM == bm && kCfgs[c].BN == bn) return c; return -1; };
+  const int big = find(128, 128), wide = find(64, 128), small = find(64, 64);
+  auto tiles_of = [&](int c) { return ((a.M + kCfgs[c].BM - 1) / kCfgs[c].BM) * ((a.N + kCfgs[c].BN - 1) / kCfgs[c].BN); };
+  auto fits = [&](int c) {
+    if (c < 0) return false;
+    if (a.act == 2 && kCfgs[c].BN != 128) return false;
+    if (a.img_rows && a.img_rows % kCfgs[c].BM != 0) return false;
+    if (a.outT && a.nt0 % kCfgs[c].BN != 0) return false;
+    return true;
+  };
+  if (fits(big) && tiles_of(big) >= 192) best = big;
+  else if (fits(wide) && a.N % 128 == 0 && tiles_of(wide) >= 128) best = wide;
+  else if (fits(small)) best = small;
+  else if (fits(wide)) best = wide;
+  else best = big;
+  int ks = 1;
+  const int nkt = a.K / 64;
+  const bool can_split = !a.outT && !a.act && !a.rowstat && !a.ln_stat && !(a.img_rows && !a.phase2) && a.slab != nullptr;
+  if (can_split && best >= 0) {
+    const int t = tiles_of(best);
+    while (ks < 16 && t * ks * 2 <= 320 && nkt / (ks * 2) >= 4) ks *= 2;
+  }
+  if (ksplit) *ksplit = ks;
+  return best;
+}
+
 static int pick_cfg(const GemmArgs& a) {
   // heuristic default (the UNet plan autotunes over all cfgs x split-K instead)
   if (a.act == 2) return a.img_rows % 128 == 0 ? 1 : 6;            // softmax epilogue: 128-wide tiles (t128x128s3 / t64x128s4)
@@ -1587,7 +1696,7 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   SDMI_REQUIRE(cfg < sdmi_gemm_num_cfgs(), "gemm: bad cfg %d", cfg);
   const bool halo = cfg >= kNumCfgs;
   const CfgInfo& c = cfg_info(cfg);
-  if (halo) SDMI_REQUIRE(halo_ok(a, c), "gemm: halo config %s not applicable to this conv", c.name);
+  if (halo) SDMI_REQUIRE(halo_ok(a, c) && !a.accurate, "gemm: halo config %s not applicable to this conv", c.name);
   SDMI_REQUIRE(c.BN % 64 == 0 || (a.ks == 3 && !a.rowstat && !a.ln_stat && !a.outT), "gemm: config %s (160-wide tile) is not applicable to this GEMM: 3x3 convs only", c.name);
   SDMI_REQUIRE(a.act != 2 || (c.BN == 128 && !halo && a.ksplit <= 1 && !a.outT && !a.out_f32 && !a.res && a.N % 128 == 0 && a.M % c.BM == 0 &&
                               a.sm_valid > 0 && a.sm_valid <= 128),
@@ -1652,6 +1761,16 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     SDMI_REQUIRE(lds <= 160 * 1024, "gemm: halo config %s needs %d B of LDS", c.name, lds);
     if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
     hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+    SDMI_CHECK_HIP(hipGetLastError());
+  } else if (a.accurate) {
+    SDMI_REQUIRE(c.kern_acc != nullptr, "gemm: config %s was not built with the wide A operand (accurate mode)", c.name);
+    SDMI_REQUIRE(a.a0f && (a.C1 == 0 || a.a1f) && (a.X0 == 0 || a.x0f) && (a.X1 == 0 || a.x1f) && !a.gna_rec,
+                 "gemm: the accurate mode needs the fp32 copy of every A source");
+    if (!g_attr_done_acc[dev][cfg]) {
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.kern_acc, hipFuncAttributeMaxDynamicSharedMemorySize, c.LDS_acc));
+      g_attr_done_acc[dev][cfg] = true;
+    }
+    hipLaunchKernelGGL(c.kern_acc, dim3(tiles * p.ksplit), dim3(c.NT), c.LDS_acc, st, p);
     SDMI_CHECK_HIP(hipGetLastError());
   } else {
     if (a.gna_rec) {

@@ -211,9 +211,10 @@ __global__ void pack_stem_kernel(const void* w, int w_f32, float* w36, int Cout,
 // 23 KB of weights for every pixel -- 190 MB per step out of L1/L2, 16 us): a lane takes (tap, 8-channel chunk) items, loads
 // the item's weights once and multiplies them with the four pixels' inputs; w packed [4][3][3][Cin] fp16.
 constexpr int FC_PX = 4;
-template <int NCO>        // output channels the kernel holds accumulators for: 4 (UNet eps, VAE image) or 8 (VAE encoder moments)
+// XF32 (accurate mode): the input is read from its fp32 copy x32 and multiplied in fp32 (v_fma) against the fp16 weights
+template <int NCO, bool XF32 = false>        // output channels the kernel holds accumulators for: 4 (UNet eps, VAE image) or 8 (VAE encoder moments)
 __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16* w, const float* bias, float* out,
-                                                         int B, int H, int W, int Cin, int Cout) {
+                                                         int B, int H, int W, int Cin, int Cout, const float* x32 = nullptr) {
   const int lane = threadIdx.x & 63;
   const unsigned grp = blockIdx.x * 4u + (threadIdx.x >> 6);          // group of FC_PX pixels (W % FC_PX == 0: launcher)
   const unsigned ngrp = (unsigned)B * H * W / FC_PX;
@@ -238,6 +239,24 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
     f16x8 wv[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) wv[co] = co < Cout ? *(const f16x8*)(w + ((size_t)co * 9 + tap) * Cin + c8 * 8) : f16x8{};
+    if constexpr (XF32) {
+      float xf[FC_PX][8];
+#pragma unroll
+      for (int px = 0; px < FC_PX; ++px) {
+        const int iw = ow0 + px + kw - 1;
+        const bool in = (unsigned)iw < (unsigned)W;
+        const float* xp = x32 + (((size_t)b * H + ih) * W + (in ? iw : 0)) * Cin + c8 * 8;
+        const f32x4 a = in ? *(const f32x4*)xp : f32x4{0.f, 0.f, 0.f, 0.f}, c = in ? *(const f32x4*)(xp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xf[px][e] = a[e]; xf[px][4 + e] = c[e]; }
+      }
+#pragma unroll
+      for (int px = 0; px < FC_PX; ++px)
+#pragma unroll
+        for (int co = 0; co < NCO; ++co)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[px][co] = fmaf(xf[px][e], (float)wv[co][e], acc[px][co]);
+    } else {
     f16x8 xv[FC_PX];
 #pragma unroll
     for (int px = 0; px < FC_PX; ++px) {
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const f16* x, const f16
 #pragma unroll
         for (int e = 0; e < 8; e += 2)      // v_dot2_f32_f16: two fp16 products + fp32 accumulate per instruction
           acc[px][co] = __builtin_amdgcn_fdot2(f16x2{xv[px][e], xv[px][e + 1]}, f16x2{wv[co][e], wv[co][e + 1]}, acc[px][co], false);
+    }
   }
 #pragma unroll
   for (int px = 0; px < FC_PX; ++px)
@@ -710,13 +730,17 @@ int sdmi_launch_stem_conv(const float* lat, int lat_batch, const float* w36, con
 }
 
 int sdmi_launch_final_conv(const f16* x, const f16* w, const float* bias, float* out, int B, int H, int W, int Cin,
-                           int Cout, hipStream_t st) {
+                           int Cout, hipStream_t st, const float* x32) {
   SDMI_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 8 && W % FC_PX == 0, "final conv: Cin=%d Cout=%d W=%d (Cout <= 8, W a multiple of %d)", Cin, Cout, W, FC_PX);
   const size_t npix = (size_t)B * H * W;
   SDMI_REQUIRE(npix < ((size_t)1 << 31), "final conv: too many pixels");
   const size_t ngrp = npix / FC_PX;
-  if (Cout <= 4) hipLaunchKernelGGL(final_conv_kernel<4>, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
-  else hipLaunchKernelGGL(final_conv_kernel<8>, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout);
+  const float* const nof = nullptr;
+  if (x32) {
+    SDMI_REQUIRE(Cout <= 4, "final conv: the fp32-input form holds 4 output channels");
+    hipLaunchKernelGGL((final_conv_kernel<4, true>), dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout, x32);
+  } else if (Cout <= 4) hipLaunchKernelGGL((final_conv_kernel<4, false>), dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout, nof);
+  else hipLaunchKernelGGL((final_conv_kernel<8, false>), dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, x, w, bias, out, B, H, W, Cin, Cout, nof);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

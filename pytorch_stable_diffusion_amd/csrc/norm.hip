@@ -196,6 +196,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     const int c = c_[k];
     const f32x4 ga = ga_[k], gb = gb_[k], ba = ba_[k], bb = bb_[k];
     f16x8 o;
+    float yf[8];
     const int g0 = c / cpg;                      // one division per item; cpg >= 4, so c+e is at most 2 groups further
     const int r0 = c - g0 * cpg;
 #pragma unroll
@@ -209,8 +210,14 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
       float y = (v[k][e] - s_mean[gg]) * s_rstd[gg] * gam + bet;
       if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));     // v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division
       o[e] = (f16)y;
+      yf[e] = y;
     }
     *(f16x8*)(p.y + ((size_t)n * p.P + px_[k]) * C + c) = o;
+    if (p.y32) {                                 // accurate mode: the conv that follows reads the fp32 values
+      float* yp = p.y32 + ((size_t)n * p.P + px_[k]) * C + c;
+      *(f32x4*)yp = f32x4{yf[0], yf[1], yf[2], yf[3]};
+      *(f32x4*)(yp + 4) = f32x4{yf[4], yf[5], yf[6], yf[7]};
+    }
   }
 }
 
@@ -337,13 +344,16 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
       const int c = g * cpg + 4 * j;
       const f32x4 ga = *(const f32x4*)(&s_gb[0][4 * j]), be = *(const f32x4*)(&s_gb[1][4 * j]);
       f16x4 o;
+      f32x4 yf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = (v[i][e] - mean) * rstd * ga[e] + be[e];
         if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
         o[e] = (f16)y;
+        yf[e] = y;
       }
       *(f16x4*)(p.y + ((size_t)n * p.P + px) * C + c) = o;
+      if (p.y32) *(f32x4*)(p.y32 + ((size_t)n * p.P + px) * C + c) = yf;
     }
     px += dpx; j += dj;
     if (j >= q4) { j -= q4; ++px; }

@@ -161,7 +161,7 @@ int final_layer(sdmi_unet* u, const Act& x, float* eps_out, const StepFuse* sf =
     u->log_launch("final_conv");
     return SDMI_OK;
   }
-  TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, 4, u->st));
+  TRY(sdmi_launch_final_conv(t.h, u->final_conv.w, u->final_conv.bias, eps_out, x.B, x.H, x.W, x.C, 4, u->st, u->accurate ? t.f : nullptr));
   u->launches += 1;
   u->log_launch("final_conv");
   return SDMI_OK;
@@ -197,6 +197,8 @@ int sdmi_unet_create(const sdmi_tensor_desc* tensors, int n_tensors, int flags, 
   u->stream_f32 = (flags & SDMI_FLAG_STREAM_F32) != 0;
   u->partial = (flags & SDMI_FLAG_PARTIAL) != 0;
   u->tune = (flags & SDMI_FLAG_NO_TUNE) == 0;
+  u->accurate = (flags & SDMI_FLAG_ACCURATE) != 0;
+  if (u->accurate) { u->ln_fold_on = false; u->tune = false; }      // (engine.h Engine::accurate)
   for (int i = 0; i < n_tensors; ++i) {
     if (!tensors[i].name || !tensors[i].data_dev) { delete u; sdmi_set_error("tensor %d: null name/data", i); return SDMI_EINVAL; }
     u->src[tensors[i].name] = tensors[i];
@@ -263,6 +265,7 @@ int sdmi_unet_clone(const sdmi_unet* src, sdmi_unet** out) {
   sdmi_unet* u = new sdmi_unet();
   u->flags = src->flags; u->stream_f32 = src->stream_f32; u->partial = src->partial; u->tune = src->tune;
   u->is_lane = true;
+  u->accurate = src->accurate;
   u->weight_bytes = 0;                                   // borrowed
   u->res = src->res; u->attn = src->attn; u->convs = src->convs;
   u->te1 = src->te1; u->te2 = src->te2; u->has_time = src->has_time; u->time_total = src->time_total;
@@ -308,6 +311,7 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
     u->ctx_batch = 0;
     u->free_ctx();
     TRY(u->dmalloc_ctx(&u->ctx16, (size_t)batch * kCtxPad * kCtx * 2));
+    if (u->accurate) TRY(u->dmalloc_ctx(&u->ctx32, (size_t)batch * kCtxPad * kCtx * 4));
     int cmax = 0;
     for (const std::string& p : u->attn_order) {
       const AttnW& w = u->attn[p];
@@ -319,7 +323,7 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
       u->ctxVt.push_back(v);
       f16 *w1 = nullptr, *w2 = nullptr;
       float *g = nullptr, *h = nullptr;
-      if (w.wqT) {
+      if (w.wqT && !u->accurate) {
         const size_t rows = (size_t)batch * Engine::kXfCols;
         TRY(u->dmalloc_ctx(&w1, rows * w.C * 2));
         TRY(u->dmalloc_ctx(&w2, rows * w.C * 2));
@@ -344,6 +348,12 @@ int sdmi_unet_set_context(sdmi_unet* u, const float* ctx_dev, int batch, int n_t
   u->ctx_tokens = n_tokens;
   Act c;
   c.h = u->ctx16; c.B = batch; c.H = kCtxPad; c.W = 1; c.C = kCtx;
+  if (u->accurate) {       // the k / v projections read the context itself, zero-padded to 80 rows like its fp16 copy
+    SDMI_CHECK_HIP(hipMemsetAsync(u->ctx32, 0, (size_t)batch * kCtxPad * kCtx * 4, u->st));
+    SDMI_CHECK_HIP(hipMemcpy2DAsync(u->ctx32, (size_t)kCtxPad * kCtx * 4, ctx_dev, (size_t)n_tokens * kCtx * 4, (size_t)n_tokens * kCtx * 4, batch,
+                                    hipMemcpyDeviceToDevice, u->st));
+    c.f = u->ctx32;
+  }
   for (size_t i = 0; i < u->attn_order.size(); ++i) {
     const AttnW& w = u->attn[u->attn_order[i]];
     { GemmArgs a = Engine::base_args(c, nullptr, w.k, kCtxPad, 1, 1, 0); a.out = u->ctxK[i]; a.ldc = w.C; TRY(u->gemm(a)); }
@@ -457,7 +467,7 @@ int sdmi_unet_denoise_step_batch(sdmi_unet* u, float* latents_dev, int n_prompts
   }
   // SDMI_STEP_FUSE=0: the output conv writes eps and cfg_ddpm_kernel makes the step (two launches; A/B and the bit-identity test)
   static const bool fuse_on = !(getenv("SDMI_STEP_FUSE") && atoi(getenv("SDMI_STEP_FUSE")) == 0);
-  if (fuse_on && w % 4 == 0) {
+  if (fuse_on && w % 4 == 0 && !u->accurate) {       // (accurate mode: the output conv reads fp32 and the step stays its own launch)
     if (!coef) { sdmi_set_error("denoise_step: null coefficients"); return SDMI_EINVAL; }
     StepFuse sf{latents_dev, noise_dev, coef, n_prompts, do_cfg, cfg_scale};
     return unet_forward_impl(u, latents_dev, n_prompts, nullptr, step_idx, nullptr, batch, h, w, stream, &sf);
@@ -617,11 +627,21 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.gna_rec = d->gna_rec; a.gna_gamma = d->gna_gamma; a.gna_beta = d->gna_beta; a.gna_eps = d->gna_eps;
   a.gna_T = d->gna_t; a.gna_parts = d->gna_parts; a.gna_atom = d->gna_atom; a.gna_rows = d->gna_rows;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
+  a.a0f = d->a0f; a.a1f = d->a1f; a.x0f = d->x0f; a.x1f = d->x1f; a.accurate = d->accurate;
+  if (a.accurate) a.a0 = a.a0 ? a.a0 : (const f16*)d->a0f;          // (the launcher's null check; never read)
+  int cfg = d->cfg;
+  if (a.accurate && cfg < 0) {
+    TRY(ensure_globals((size_t)16 * a.M * a.N * 4));
+    a.slab = g_slab;
+    int ks = 1;
+    cfg = sdmi_gemm_pick_acc_cfg(a, &ks);
+    if (d->ksplit <= 1) a.ksplit = ks;
+  }
   TRY(ensure_globals(a.ksplit > 1 ? (size_t)a.ksplit * a.M * a.N * 4 : 0));
   a.zero = g_zero; a.slab = g_slab;
   int T = 0, parts = 0;
   TRY(gacc_layout(d, a, &T, &parts));
-  return sdmi_launch_gemm(a, d->cfg < 0 ? sdmi_gemm_pick_cfg(a) : d->cfg, (hipStream_t)stream);
+  return sdmi_launch_gemm(a, cfg < 0 ? sdmi_gemm_pick_cfg(a) : cfg, (hipStream_t)stream);
 }
 int sdmi_op_gemm_stat_layout(const sdmi_gemm_desc* d, int* T, int* parts) {
   if (!d || !T || !parts) { sdmi_set_error("op_gemm_stat_layout: null argument"); return SDMI_EINVAL; }

@@ -17,7 +17,7 @@ from ._util import normalize_device
 class Diffusion:
     _GUARD_EARLY = 3     # steps after which a denoising loop first reads the LayerNorm-fold guard's counter
 
-    def __init__(self, stream_f32: bool = True, autotune: bool = True):
+    def __init__(self, stream_f32: bool = True, autotune: bool = True, accurate: bool = False):
         self._manifest = arch.diffusion_manifest()
         self._state: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._device = torch.device("cpu")
@@ -32,6 +32,10 @@ class Diffusion:
         self.ln_guard_fallbacks = 0
         self.stream_f32 = stream_f32
         self.autotune = autotune
+        # accurate=True (include/sdmi.h SDMI_FLAG_ACCURATE): every GEMM / conv multiplies its activations as hi + lo fp16 pairs read
+        # from fp32 tensors -- what remains of the fp16 path's error is the weights' own rounding.  Several times slower; for
+        # validation and for weight laws on which fp16 activations miss the 1e-3 pixel tolerance.
+        self.accurate = accurate
 
     # ---- nn.Module-like surface used by the reference (model_loader.py:36-38, pipeline.py:199-200) --
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
@@ -98,7 +102,7 @@ class Diffusion:
             return self._lanes[index]
         ln = Diffusion.__new__(Diffusion)
         ln._manifest, ln._state, ln._device = self._manifest, self._state, self._device
-        ln.stream_f32, ln.autotune = self.stream_f32, self.autotune
+        ln.stream_f32, ln.autotune, ln.accurate = self.stream_f32, self.autotune, self.accurate
         ln._ctx_key = None
         ln._lanes = []
         ln.ln_guard_hits, ln.ln_guard_fallback = 0, self.ln_guard_fallback
@@ -128,7 +132,8 @@ class Diffusion:
                                    "call .to('cuda') first (there is no CPU fallback)")
             if len(self._state) != len(self._manifest):
                 raise RuntimeError("Diffusion: weights not loaded")
-            flags = (_native.FLAG_STREAM_F32 if self.stream_f32 else 0) | (0 if self.autotune else _native.FLAG_NO_TUNE)
+            flags = ((_native.FLAG_STREAM_F32 if self.stream_f32 else 0) | (0 if self.autotune else _native.FLAG_NO_TUNE)
+                     | (_native.FLAG_ACCURATE if getattr(self, "accurate", False) else 0))
             with torch.cuda.device(self._device):
                 self._handle = _native.UNetHandle(self._state, flags)
         return self._handle

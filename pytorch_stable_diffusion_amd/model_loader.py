@@ -16,12 +16,13 @@ from .diffusion import Diffusion
 from .vae import VAE_Decoder, VAE_Encoder
 
 
-def preload_models_from_state_dicts(state_dicts: Dict[str, Dict[str, torch.Tensor]], device) -> Dict[str, object]:
+def preload_models_from_state_dicts(state_dicts: Dict[str, Dict[str, torch.Tensor]], device, accurate: bool = False) -> Dict[str, object]:
+    """accurate=True: the UNet runs the wide-operand kernels (``Diffusion(accurate=True)``, include/sdmi.h SDMI_FLAG_ACCURATE)."""
     encoder = VAE_Encoder().to(device)
     encoder.load_state_dict(state_dicts["encoder"], strict=True)
     decoder = VAE_Decoder().to(device)
     decoder.load_state_dict(state_dicts["decoder"], strict=True)
-    diffusion = Diffusion().to(device)
+    diffusion = Diffusion(accurate=accurate).to(device)
     diffusion.load_state_dict(state_dicts["diffusion"], strict=True)
     clip = CLIP().to(device)
     clip.load_state_dict(state_dicts["clip"], strict=True)

@@ -49,7 +49,7 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
           w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None, gstat_rows_img=0, gstat_atom=10, ln_guard=None,
-          ln_guard_sigma=8.0, gna=None):
+          ln_guard_sigma=8.0, gna=None, accurate=False, a0f=None, a1f=None, x0f=None, x1f=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given).
     gstat_rows_img > 0: the launch also leaves the GroupNorm statistics of its output (sdmi_gemm_desc::gacc); they are returned
     in LAST_STAT = (records [images][T][atoms][parts][2] fp32, T, parts).  ValueError if the config cannot take them."""
@@ -94,6 +94,11 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
         rec, gamma, beta, eps, rows = gna
         d.gna_rec, d.gna_gamma, d.gna_beta, d.gna_eps = rec.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps
         d.gna_t, d.gna_parts, d.gna_atom, d.gna_rows = rec.shape[1], rec.shape[3], c0 // rec.shape[2], rows
+    if accurate:               # the wide-operand kernels: fp32 copies of every A source (a0 / a1 / x0 / x1 only give the shapes)
+        d.accurate = 1
+        d.a0f = a0f.data_ptr(); d.a1f = 0 if a1f is None else a1f.data_ptr()
+        d.x0f = 0 if x0f is None else x0f.data_ptr(); d.x1f = 0 if x1f is None else x1f.data_ptr()
+        assert a0f.dtype == torch.float32 and tuple(a0f.shape) == tuple(a0.shape)
     if gstat_rows_img:
         d.gacc, d.gacc_atom, d.gacc_rows_img = 16, gstat_atom, gstat_rows_img          # (any non-null pointer for the layout query)
         T, parts = C.c_int(0), C.c_int(0)

@@ -341,3 +341,88 @@ def test_run_prompts_lanes_of_batched_groups_match_one_lane(models):
         assert a.shape == (256, 256, 3) and torch.equal(a, b)
     assert not torch.equal(two[0], two[1])
     m["diffusion"].release_lanes()
+
+
+class TapAll:
+    """decoder wrapper that keeps the float image of EVERY call (generate_batch decodes its prompts one by one)"""
+
+    def __init__(self, inner):
+        self.inner, self.all = inner, []
+
+    def to(self, d):
+        self.inner.to(d)
+        return self
+
+    def __call__(self, *a):
+        out = self.inner(*a)
+        self.all.append(out.clone())
+        return out
+
+
+_P6_PROMPTS = ["a dog", "a red car by the sea", "a cat on a mat", "two birds", "the sea at night", "a house on a hill"]
+_P6_MORE = ["a tree", "a boat", "a street in the rain", "a bowl of fruit", "a mountain lake", "an old bridge"]
+
+
+@pytest.fixture(scope="module")
+def p6_batch(models):
+    """What bench.py's default throughput leg runs -- SIX prompts through one batched chain (UNet batch 12, the M = 49152 plans),
+    BASELINE configs[1]'s 50 steps at 512x512 -- as pipeline.generate_batch, once for the tests below."""
+    from pytorch_stable_diffusion_amd import pipeline
+    m = dict(models)
+    tap = TapAll(models["decoder"].inner)
+    m["decoder"] = tap
+    kw = dict(do_cfg=True, cfg_scale=7.5, sampler_name="ddpm", n_inference_steps=50, models=m, device=DEV, idle_device=None,
+              tokenizer=StubTokenizer())
+    got = pipeline.generate_batch(_P6_PROMPTS, uncond_prompt="", seeds=[42 + i for i in range(6)], **kw)
+    cap, peak = m["diffusion"].handle().arena()
+    G.log_metric(test="generate_batch_p6", arena_GiB=cap / 2**30, arena_peak_GiB=peak / 2**30, ln_guard_hits=m["diffusion"].ln_guard_hits)
+    return got, tap.all, m, kw
+
+
+def test_generate_batch_six_prompts_50_steps_prompt0_vs_reference(p6_batch):
+    """Prompt 0 of the six-prompt batched chain is the reference golden's prompt and seed ("a dog", 42): its image against the
+    reference's OWN 50-step CPU generate() (tests/golden/e2e50.npz) at the single-prompt bounds -- north_star's pixel MAE < 1e-3 on
+    the float image (4x subsample and full resolution), uint8 within U8_MAX."""
+    got, floats, m, _ = p6_batch
+    assert len(got) == 6 and len(floats) == 6
+    assert m["diffusion"].ln_guard_hits == 0 and not m["diffusion"].ln_guard_fallback_ran
+    _check("txt50", got[0], floats[0], H.load_npz("e2e50.npz"))
+
+
+def test_generate_batch_six_prompts_50_steps_vs_single_prompt_runs(p6_batch):
+    """The other five prompts of that batch against their own single-prompt generate() calls (same seed, same noise stream, same
+    CLIP / VAE): two fp16 paths whose GEMMs ran other tile plans (M = 49152 instead of 8192), each ~6.5e-4 from the reference."""
+    from pytorch_stable_diffusion_amd import pipeline
+    got, _, m, kw = p6_batch
+    worst = 0.0
+    for i in range(1, 6):
+        one = pipeline.generate(prompt=_P6_PROMPTS[i], uncond_prompt="", input_image=None, strength=0.8, seed=42 + i, **kw)
+        d = np.abs(got[i].astype(np.int32) - one.astype(np.int32))
+        G.log_metric(test="generate_batch_p6", prompt=_P6_PROMPTS[i], u8_max=int(d.max()), u8_mean=float(d.mean()))
+        worst = max(worst, d.mean() / 255.0)
+        assert d.max() <= U8_MAX + 1 and d.mean() / 255.0 < 1.5 * PIXEL_MAE, f"{_P6_PROMPTS[i]}: batched vs single uint8 max diff {d.max()}, mean {d.mean():.3f}"
+    assert len({g.tobytes() for g in got}) == 6                     # six different images
+
+
+def test_run_prompts_two_lanes_of_six_prompt_chains_50_steps(p6_batch):
+    """bench.py's other default leg as the generate()-level launcher runs it: run_prompts(streams_per_gpu=2, batch_per_gpu=6), twelve
+    prompts, 50 steps.  Lane 0's group is the batch above (same prompts, seeds 42..47): bit for bit the images of the one-lane
+    generate_batch call (a lane runs the same kernels and plans over the same packed weights), so prompt 0 carries the reference
+    check with it; lane 1's group runs concurrently and two of its prompts are checked against their single-prompt runs."""
+    from pytorch_stable_diffusion_amd import pipeline, replicas
+    got, _, m, kw = p6_batch
+    prompts = _P6_PROMPTS + _P6_MORE
+    imgs, st = replicas.run_prompts(prompts, m, StubTokenizer(), DEV, seed_base=42, n_inference_steps=50, streams_per_gpu=2, batch_per_gpu=6)
+    assert st["streams_per_gpu"] == 2 and st["batch_per_gpu"] == 6 and len(imgs) == 12
+    assert st["ln_guard_hits"] == 0 and st["ln_guard_fallbacks"] == 0
+    for i in range(6):
+        assert torch.equal(imgs[i], torch.from_numpy(got[i])), f"prompt {i}: the lane's batched chain differs from the one-lane generate_batch"
+    g = H.load_npz("e2e50.npz")
+    d0 = np.abs(imgs[0].numpy().astype(np.int32) - g["txt50_u8"].astype(np.int32))
+    assert d0.max() <= U8_MAX and d0.mean() / 255.0 < PIXEL_MAE, f"prompt 0 vs the reference: max {d0.max()}, MAE {d0.mean() / 255:.2e}"
+    for i in (6, 11):
+        one = pipeline.generate(prompt=prompts[i], uncond_prompt="", input_image=None, strength=0.8, seed=42 + i, **kw)
+        d = np.abs(imgs[i].numpy().astype(np.int32) - one.astype(np.int32))
+        G.log_metric(test="run_prompts_2x6", prompt=prompts[i], u8_max=int(d.max()), u8_mean=float(d.mean()))
+        assert d.max() <= U8_MAX + 1 and d.mean() / 255.0 < 1.5 * PIXEL_MAE, f"{prompts[i]}: {d.max()} / {d.mean():.3f}"
+    m["diffusion"].release_lanes()

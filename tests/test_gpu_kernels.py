@@ -140,6 +140,74 @@ def test_conv_implicit_gemm(case):
         assert n_halo > 0, "no halo-reuse config ran on an eligible conv"
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=16, W=16, C0=128, C1=0, Co=128, ks=3, stride=1, ups=0, X0=0, X1=0),
+    dict(B=2, H=12, W=12, C0=128, C1=64, Co=320, ks=3, stride=1, ups=0, X0=0, X1=0),     # concat, ragged tiles
+    dict(B=1, H=10, W=6, C0=64, C1=128, Co=72, ks=1, stride=1, ups=0, X0=0, X1=0),       # 1x1 on concat
+    dict(B=2, H=9, W=9, C0=64, C1=0, Co=64, ks=3, stride=2, ups=0, X0=0, X1=0),          # stride 2
+    dict(B=2, H=8, W=8, C0=128, C1=0, Co=64, ks=3, stride=1, ups=1, X0=0, X1=0),         # x2-upsampled input
+    dict(B=2, H=12, W=12, C0=128, C1=0, Co=192, ks=3, stride=1, ups=0, X0=128, X1=64),   # fused 1x1 skip segment over two sources
+    dict(B=2, H=32, W=32, C0=320, C1=0, Co=320, ks=1, stride=1, ups=0, X0=0, X1=0),      # plain GEMM path
+])
+def test_accurate_gemm_wide_activation_operand(case):
+    """The accurate mode's GEMM (include/sdmi.h sdmi_gemm_desc::accurate, csrc/gemm.hip igemm_kernel<.., ACC>): the activation operand
+    read from fp32 tensors and multiplied as a hi + lo fp16 pair.  Inputs with a wide dynamic range (rows scaled over three decades,
+    a large common offset: what fp16 storage loses most on); against the fp64 product of the SAME fp32 activations and fp16
+    weights the error has to be that of fp32 accumulation (~1e-6 of the output scale), where the fp16-operand kernel on the rounded
+    activations sits three orders above.  Every tile built with the variant, one-pass and split-K, and the mode's own plan."""
+    c = case
+    g = torch.Generator().manual_seed(c["C0"] * 3 + c["Co"] + c["X0"])
+    scale = torch.exp(torch.rand((c["B"], c["H"], c["W"], 1), generator=g) * 6.9 - 3.45)          # 0.03 .. 30 per pixel
+    mk = lambda ch: (torch.randn((c["B"], c["H"], c["W"], ch), generator=g) * scale + 3.0 * scale)
+    x0 = mk(c["C0"])
+    x1 = mk(c["C1"]) if c["C1"] else None
+    cin = c["C0"] + c["C1"]
+    w = (torch.randn((c["Co"], cin, c["ks"], c["ks"]), generator=g) / math.sqrt(cin * c["ks"] ** 2)).half().float()
+    xin = x0 if x1 is None else torch.cat([x0, x1], -1)
+    ref = _conv_ref_f64(xin, w, c["stride"], c["ups"])
+    wp = G.pack_conv(w.to(DEV))
+    kw = {}
+    if c["X0"]:
+        e0 = mk(c["X0"])
+        e1 = mk(c["X1"]) if c["X1"] else None
+        ws = (torch.randn((c["Co"], c["X0"] + c["X1"], 1, 1), generator=g) / math.sqrt(c["X0"] + c["X1"])).half().float()
+        ref = ref + _conv_ref_f64(e0 if e1 is None else torch.cat([e0, e1], -1), ws, 1, 0)
+        wp = torch.cat([wp, G.pack_conv(ws.to(DEV))], 1).contiguous()
+        kw = dict(x0=e0.half().to(DEV), x0f=e0.to(DEV), x1=None if e1 is None else e1.half().to(DEV), x1f=None if e1 is None else e1.to(DEV))
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    sc = ref.abs().mean().item()
+    args = dict(B=c["B"], Hs=c["H"], Ws=c["W"], Ho=Ho, Wo=Wo, ks=c["ks"], stride=c["stride"], ups=c["ups"], out_f32=True,
+                a1=None if x1 is None else x1.half().to(DEV), **kw)
+    # the fp16-operand kernel on the rounded activations: the yardstick
+    plain_kw = {k: v for k, v in args.items() if not k.endswith("f")}
+    base = G.igemm(x0.half().to(DEV), wp, **plain_kw)
+    base_err = (base.cpu().double().view(ref.shape) - ref).abs().max().item() / sc
+    lib = N_.load()
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    ran = 0
+    for cfg in [-1] + _plain_cfgs():
+        for ksplit in (1, 3):
+            try:
+                out = G.igemm(x0.half().to(DEV), wp, accurate=True, a0f=x0.to(DEV), a1f=None if x1 is None else x1.to(DEV), cfg=cfg,
+                              ksplit=ksplit, **args)
+            except ValueError as exc:
+                assert "wide A operand" in str(exc), exc
+                continue
+            ran += 1
+            err = (out.cpu().double().view(ref.shape) - ref).abs().max().item() / sc
+            G.log_metric(test="accurate_gemm", case=str(c), cfg=names[cfg] if cfg >= 0 else "auto", ksplit=ksplit, err=err, fp16_operand_err=base_err)
+            assert err < 2e-5 and err < base_err / 20, f"{c} cfg {cfg} ksplit {ksplit}: err {err:.2e} of the output scale (fp16 operands: {base_err:.2e})"
+    assert ran >= 6, ran
+
+
+def _conv_ref_f64(x_nhwc, w_oihw, stride, ups):
+    x = x_nhwc.double().permute(0, 3, 1, 2)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    ks = w_oihw.shape[-1]
+    return F.conv2d(x, w_oihw.double(), stride=stride, padding=1 if ks == 3 else 0).permute(0, 2, 3, 1)
+
+
 @pytest.mark.parametrize("X0,X1,H,W", [(64, 0, 16, 16), (128, 64, 12, 12), (192, 128, 8, 8)])
 def test_conv_with_fused_skip_segment(X0, X1, H, W):
     """conv_merged 3x3 + residual_layer 1x1 over the block input (two concat sources) in one accumulator

@@ -8,7 +8,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 export SDMI_LAUNCH_LOG=$PWD/$out/launch_log.txt
-B="python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency --no-throughput"
+B="python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency --no-throughput --no-accurate"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/bench_trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- $B > /dev/null 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- $B > /dev/null 2> $out/write.err
@@ -38,7 +38,7 @@ for f in ("hbm_traffic_by_shape.json", "mfma_busy.json", "mfma_ops.json", "step_
     j = json.load(open(f"{out}/{f}"))
     j["lib_hash"] = lib_hash
     j["bench_launches_per_step"] = n
-    j["bench_command"] = "python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency --no-throughput (under rocprofv3 --pmc ...)"
+    j["bench_command"] = "python3 bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-image-latency --no-throughput --no-accurate (under rocprofv3 --pmc ...)"
     j["family_definition"] = "mfma = igemm_kernel + conv3_halo_kernel + b2b_kernel; finalize = splitk_finalize; attn; norm = GroupNorm / LayerNorm kernels; other"
     json.dump(j, open(f"{out}/{f}", "w"), indent=1)
 print("launches/step", n)

@@ -6,7 +6,7 @@ out=$1; what=${2:-bench}
 mkdir -p $out/pc
 export SDMI_RETUNE=1 SDMI_PLAN_CACHE_DIR=$PWD/$out/pc
 if [ "$what" = bench ]; then
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-throughput > $out/bench64.json
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-throughput --no-accurate > $out/bench64.json
   echo "bench 64 done"; wc -l $out/pc/*.txt
   python bench.py --latent 96 --steps 10 --warmup 3 --no-cpu-baseline --no-image-latency > $out/bench96.json
   echo "bench 96 done"; wc -l $out/pc/*.txt
