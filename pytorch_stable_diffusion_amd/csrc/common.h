@@ -161,6 +161,16 @@ void sdmi_set_error(const char* fmt, ...);
 //   optional nearest x2 upsample, ks x ks taps with stride/pad (ks = 1 -> plain GEMM).
 //   k is ordered (kh, kw, ci); W is packed [N][K] fp16 with K contiguous.
 // ---------------------------------------------------------------------------------------------
+// GroupNorm(32) (+SiLU) of the A operand applied INSIDE the halo-reuse 3x3 conv (gemm.hip conv3_halo_kernel<.., GN>): the
+// reference's "GroupNorm -> SiLU -> conv3x3" (sd/diffusion.py:173-179,199-205) as ONE launch.  The raw sources x0 | x1 (NHWC, dense,
+// C0 | C1 channels, fp32 or fp16) replace a0 / a1; the statistics are the records their producers left (GnRec layout: T record
+// rows per image, parts, atoms of `atom` channels, per source); gamma / beta over the C0 + C1 concat channels.
+struct HaloGn {
+  const void* x0; const void* x1; int in_f32; int C0, C1;
+  const float* gamma; const float* beta; float eps; int silu;
+  const float* rec0; const float* rec1; int T0, T1, P0, P1, atom;
+};
+
 struct GemmArgs {
   const f16* a0;
   const f16* a1;       // second concat source or nullptr
@@ -257,7 +267,9 @@ struct GemmArgs {
   // the tile configs built with the variant take it (sdmi_gemm_acc_ok); no halo kernel, no GroupNorm on the fragments.
   const float* a0f; const float* a1f; const float* x0f; const float* x1f;
   int accurate;
+  HaloGn hgn;          // hgn.x0 != nullptr: see HaloGn (halo configs built with the variant only: sdmi_gemm_hgn_ok)
 };
+bool sdmi_gemm_hgn_ok(const GemmArgs& a, int cfg);         // this halo config can normalise its own A operand for this conv (shape, LDS)
 bool sdmi_gemm_acc_ok(int cfg);                              // this tile config was built with the wide-operand variant
 int sdmi_gemm_pick_acc_cfg(const GemmArgs& a, int* ksplit);  // the accurate mode's tile and split-K factor for a shape (heuristic; slab_bytes = room for slabs)
 // can the one-pass epilogue of tile config `cfg` accumulate the GroupNorm statistics of this GEMM? (gemm.hip)

@@ -1007,11 +1007,25 @@ struct HCfg {
   static_assert(NS == 3 || NS == 4, "ring depth");
 };
 
-template <class C>
+// GN (round 5; GemmArgs::hgn): the conv's A operand is GroupNorm(32)(+SiLU) of the raw tensor(s) hgn.x0 | hgn.x1, applied by the
+// PRODUCER waves on the way into the halo image -- "GroupNorm -> SiLU -> conv3x3" of sd/diffusion.py:173-179,199-205 as one launch,
+// no normalised intermediate in memory:
+//   * prologue (all waves): the statistics records the producers of x0 / x1 left (GnRec) are summed to mean / rstd per group in
+//     fp64, as gn_apply_kernel of norm.hip sums them, and folded with gamma / beta into a per-channel {a, b} table in LDS
+//     (y = a x + b), all C0 + C1 channels of this tile's image;
+//   * first chunk: the producer waves load their halo pieces to registers, normalise, write the fp16 image;
+//   * steady state: the RAW piece of chunk c+1 goes to a small per-wave staging ring by LDS-DMA (fp32: two 1 KiB instructions,
+//     fp16: one + a dummy, so the counted vmcnt of the weight ring keeps a constant group size) and is normalised LDS -> LDS
+//     NS-2 intervals later, when the ring's counted wait has covered it -- each lane rewrites the 16 bytes it fetched itself, so
+//     no extra barrier; border pixels stay zero (the conv pads the NORMALISED tensor).
+// The halo image, the fragment reads and the MFMA loop are the plain kernel's: same sums in the same order on the same fp16
+// values gn_apply_kernel would have written.
+template <class C, bool GN = false>
 __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_bytes) {
   sdmi_kernarg_warm<sizeof(GemmArgs) + 24>();     // + halo_bytes + the hidden grid size (gridDim.x)
   constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT, NS = C::NS;
-  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = C::G, NTAPH = C::NTAPH;
+  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = C::G + (GN ? 1 : 0), NTAPH = C::NTAPH;      // GN: two raw-piece DMAs per interval
+  constexpr int GD = NS - 2, GSLOTS = GD + 1;      // GN: intervals between a raw piece's DMA and its normalisation; staging slots per wave
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long clk_setup = 0;
@@ -1056,6 +1070,73 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   char* hb1 = smem + halo_bytes;
   char* bring = smem + 2 * halo_bytes;
   char* dump = bring + NS * C::B_BYTES;
+  // GN: [dump 1 KiB][staging: NW waves x GSLOTS x 2 KiB][table: {a, b} per channel][mean | rstd: 64 floats]
+  char* const gstage = dump + 1024;
+  float* const gtab = (float*)(gstage + NW * GSLOTS * 2048);
+  if constexpr (GN) {
+    const HaloGn& g = p.hgn;
+    const int cpg = Cin >> 5, apg = cpg / g.atom, na0 = g.C0 / g.atom, na1 = g.C1 / g.atom;
+    float* const s_ms = gtab + 2 * Cin;
+    double* const s_red = (double*)hb1;                 // (the second halo buffer is idle until the first chunk is being multiplied)
+    constexpr int SH = NT / 32;                         // shares per group
+    constexpr int NCH = (2560 + NT - 1) / NT;           // channels per thread of the table
+    float gm[NCH], bt[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {                     // gamma / beta come from HBM (every weight is read once per step): requested first
+      const int c = tid + k * NT;
+      gm[k] = c < Cin ? g.gamma[c] : 0.f;
+      bt[k] = c < Cin ? g.beta[c] : 0.f;
+    }
+    {
+      const int gi = tid & 31, sl = tid >> 5;
+      const int npair = apg * max(g.T0, g.T1);          // (atom of the group, record row) pairs; this thread: sl, sl + SH, ...
+      auto rec_of = [&](int f, f32x4& v) {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f >= npair) return;
+        const int t = f / apg, a = gi * apg + (f - t * apg);           // atom index in concat channel space
+        const bool second = a >= na0;
+        const int T = second ? g.T1 : g.T0, parts = second ? g.P1 : g.P0;
+        if (t >= T) return;
+        const float* rr = (second ? g.rec1 : g.rec0) + ((size_t)(img * T + t) * (second ? na1 : na0) + (second ? a - na0 : a)) * parts * 2;
+        if (parts == 2) v = *(const f32x4*)rr;
+        else { const f32x2 u = *(const f32x2*)rr; v[0] = u[0]; v[1] = u[1]; }
+      };
+      constexpr int MAXR = 6;                           // in flight at once (a concat of two 32-row-block sources at C = 640: 4 per share)
+      f32x4 rv[MAXR];
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) rec_of(sl + SH * k, rv[k]);
+      double su = 0.0, sq = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) { su += (double)rv[k][0] + (double)rv[k][2]; sq += (double)rv[k][1] + (double)rv[k][3]; }
+      for (int f = sl + SH * MAXR; f < npair; f += SH) { f32x4 v; rec_of(f, v); su += (double)v[0] + (double)v[2]; sq += (double)v[1] + (double)v[3]; }
+      s_red[(sl * 32 + gi) * 2] = su;
+      s_red[(sl * 32 + gi) * 2 + 1] = sq;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      double su = 0.0, sq = 0.0;
+#pragma unroll
+      for (int k = 0; k < SH; ++k) { su += s_red[(k * 32 + tid) * 2]; sq += s_red[(k * 32 + tid) * 2 + 1]; }
+      const double cnt = (double)cpg * (double)(Hh * W);
+      const double mean = su / cnt;
+      double var = sq / cnt - mean * mean;               // E[x^2] - E[x]^2 in fp64 above the fp32 records (norm.hip gn_apply_kernel)
+      var = var < 0.0 ? 0.0 : var;
+      s_ms[tid] = (float)mean;
+      s_ms[32 + tid] = rsqrtf((float)var + g.eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = tid + k * NT;
+      if (c < Cin) {
+        const int gg = c / cpg;
+        const float a = s_ms[32 + gg] * gm[k];
+        gtab[2 * c] = a;
+        gtab[2 * c + 1] = bt[k] - s_ms[gg] * a;
+      }
+    }
+    __syncthreads();                                    // table complete; hb1 free again
+  }
 
   const int r = lane & 31, h = lane >> 5;
   f32x16 acc[FM][FN];
@@ -1095,6 +1176,62 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       const f16* g = h_in[t] ? base + ((size_t)h_pix[t] * ld + cc + h_gch[t]) : gz;
       glds16(lds_off >= 0 ? g : gz, lds_off >= 0 ? hb + lds_off : dump);
     };
+    // ---- GN: raw piece -> normalised fp16 piece ----
+    // byte address of this lane's 8 raw channels of piece t in chunk `chunk` (nullptr: border pixel / no such piece)
+    auto raw_src = [&](int t, int chunk) -> const char* {
+      const int cabs = chunk << 6;
+      const bool second = cabs >= p.hgn.C0;
+      const char* base = (const char*)(second ? p.hgn.x1 : p.hgn.x0);
+      const int ld = second ? p.hgn.C1 : p.hgn.C0;
+      const int cc = second ? cabs - p.hgn.C0 : cabs;
+      const size_t el = (size_t)h_pix[t] * ld + cc + h_gch[t];
+      return (h_in[t] && h_lds[t] >= 0) ? base + el * (p.hgn.in_f32 ? 4 : 2) : nullptr;
+    };
+    // y = SiLU(a x + b) of the lane's 8 channels (table entries of concat channels chunk*64 + gch ..), zero outside the image,
+    // written where the LDS-DMA of the plain kernel would have put the lane's 16 bytes
+    auto norm_store = [&](int t, int chunk, char* hb, const float (&x)[8]) {
+      const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
+      if (lds_off < 0) return;
+      const float* tp = gtab + 2 * ((chunk << 6) + h_gch[t]);
+      f32x4 tv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tv[k] = *(const f32x4*)(tp + 4 * k);          // {a0 b0 a1 b1} ...
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = fmaf(x[e], tv[e >> 1][2 * (e & 1)], tv[e >> 1][2 * (e & 1) + 1]);
+        if (p.hgn.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
+        o[e] = h_in[t] ? (f16)y : (f16)0.f;
+      }
+      *(f16x8*)(hb + lds_off + lane * 16) = o;
+    };
+    char* const my_stage = gstage + wave * (GSLOTS * 2048);
+    auto raw_dma = [&](int t, int chunk, int slot) {      // two LDS-DMA instructions, always (constant group size for the counted waits)
+      const char* src = raw_src(t, chunk);
+      char* sl = my_stage + slot * 2048;
+      const char* z = (const char*)p.zero + (lane & 7) * 16;
+      if (p.hgn.in_f32) {
+        glds16(src ? src : z, sl);
+        glds16(src ? src + 16 : z, sl + 1024);
+      } else {
+        glds16(src ? src : z, sl);
+        glds16(z, dump);
+      }
+    };
+    auto norm_from_stage = [&](int t, int chunk, char* hb, int slot) {
+      const char* sl = my_stage + slot * 2048 + lane * 16;
+      float x[8];
+      if (p.hgn.in_f32) {
+        const f32x4 u0 = *(const f32x4*)sl, u1 = *(const f32x4*)(sl + 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = u0[e]; x[4 + e] = u1[e]; }
+      } else {
+        const f16x8 u = *(const f16x8*)sl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)u[e];
+      }
+      norm_store(t, chunk, hb, x);
+    };
     // ---- weight tile pointers: w[n][tap*Cin + chunk*64 + ...] ----
     const f16* b_ptr[RB];
     int b_ok[RB];
@@ -1118,15 +1255,47 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       if (++tap == 9) { tap = 0; ++chunk; }
     };
     // prologue: whole halo of the first chunk + first NS-1 weight tiles
+    if constexpr (GN) {
+      // the first chunk's pieces through registers (all of this wave's loads in flight at once), the weight tiles behind them
+      f32x4 r0[NTAPH], r1[NTAPH];
+#pragma unroll
+      for (int t = 0; t < NTAPH; ++t) {
+        const char* src = raw_src(t, c_first);
+        r0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; r1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (src) {
+          r0[t] = *(const f32x4*)src;
+          if (p.hgn.in_f32) r1[t] = *(const f32x4*)(src + 16);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NS - 1; ++s2)
+        if (s2 < nk) stage_b(s2);
+#pragma unroll
+      for (int t = 0; t < NTAPH; ++t) {
+        float x[8];
+        if (p.hgn.in_f32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] = r0[t][e]; x[4 + e] = r1[t][e]; }
+        } else {
+          const f16x8 u = __builtin_bit_cast(f16x8, r0[t]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = (float)u[e];
+        }
+        norm_store(t, c_first, hb0, x);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
     for (int t = 0; t < NTAPH; ++t) halo_piece(t, c_first, hb0);
 #pragma unroll
     for (int s2 = 0; s2 < NS - 1; ++s2)
       if (s2 < nk) stage_b(s2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     int nxt = NS - 1;
     int ctap = 0, cchunk = c_first;                   // (chunk, tap) being CONSUMED in interval t
+    int gslot = 0, dslot = 0, dtap = 0, dchunk = c_first;   // GN: staging slot of interval t; slot / (chunk, tap) of interval t - GD
 #ifdef SDMI_CLK_PROBE_FINE
     unsigned long long acc_issue = 0, acc_vm = 0, acc_bar = 0;
 #endif
@@ -1141,9 +1310,13 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
         if (ctap < NTAPH && have_next) {
 #pragma unroll
           for (int tt = 0; tt < NTAPH; ++tt)
-            if (tt == ctap) halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
+            if (tt == ctap) {
+              if constexpr (GN) raw_dma(tt, cchunk + 1, gslot);
+              else halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
+            }
         } else {
           glds16(p.zero, dump);
+          if constexpr (GN) glds16(p.zero, dump);
         }
       }
 #ifdef SDMI_CLK_PROBE_FINE
@@ -1156,6 +1329,22 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s2 = __builtin_amdgcn_s_memtime();
 #endif
+      if constexpr (GN) {
+        // the raw piece requested GD intervals ago is covered by the wait above (vmcnt(GD x G) leaves only younger groups in
+        // flight, and the tail's waits are stricter): normalise it into the next chunk's image.  Pieces are requested in taps
+        // 0 .. NTAPH-1 = 8-GD of a chunk, so the last one is written in tap 8, behind the barrier that ends the chunk.
+        if (t >= GD && dtap < NTAPH && (dchunk + 1) * 9 < kt1) {
+#pragma unroll
+          for (int tt = 0; tt < NTAPH; ++tt)
+            if (tt == dtap) norm_from_stage(tt, dchunk + 1, ((dchunk + 1 - c_first) & 1) ? hb1 : hb0, dslot);
+        }
+        if (t >= GD) {
+          if (++dtap == 9) { dtap = 0; ++dchunk; }
+          dslot = (dslot + 1 == GSLOTS) ? 0 : dslot + 1;
+        }
+        gslot = (gslot + 1 == GSLOTS) ? 0 : gslot + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
 #ifdef SDMI_CLK_PROBE_FINE
       acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += __builtin_amdgcn_s_memtime() - s2;
@@ -1453,6 +1642,7 @@ struct CfgInfo {
   void (*kern_gna)(GemmArgs);     // the same tile with GroupNorm on the A fragments (GemmArgs::gna_rec), or nullptr
   void (*kern_acc)(GemmArgs);     // the same tile with the fp32 A operand as a hi + lo fp16 pair (GemmArgs::accurate), or nullptr
   int LDS_acc;
+  void (*hkern_gn)(GemmArgs, int); // halo kernel that normalises its own A operand (GemmArgs::hgn), or nullptr
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
@@ -1521,11 +1711,16 @@ const CfgInfo kCfgs[] = {
 };
 #define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
   {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
-   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW}
+   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, nullptr}
+// ("N": also built with GroupNorm(+SiLU) applied to its own A operand, GemmArgs::hgn -- the tiles the 64x64 / 32x32 / 16x16
+// convs of a step are planned with)
+#define CFG_ENTRY_HN(BM, BN, WM, WN, NS) \
+  {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
+   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>, true>}
 const CfgInfo kHaloCfgs[] = {
-    CFG_ENTRY_H(128, 128, 2, 2, 3), CFG_ENTRY_H(128, 64, 2, 2, 3), CFG_ENTRY_H(64, 64, 2, 2, 3), CFG_ENTRY_H(64, 128, 2, 2, 3),
-    CFG_ENTRY_H(256, 128, 4, 2, 3), CFG_ENTRY_H(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
-    CFG_ENTRY_H(128, 160, 4, 1, 3),
+    CFG_ENTRY_HN(128, 128, 2, 2, 3), CFG_ENTRY_H(128, 64, 2, 2, 3), CFG_ENTRY_H(64, 64, 2, 2, 3), CFG_ENTRY_H(64, 128, 2, 2, 3),
+    CFG_ENTRY_HN(256, 128, 4, 2, 3), CFG_ENTRY_HN(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
+    CFG_ENTRY_HN(128, 160, 4, 1, 3),
 };
 constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -1533,6 +1728,7 @@ constexpr int kMaxDev = 16;
 bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo] = {};   // hipFuncSetAttribute is per device
 bool g_attr_done_gna[kMaxDev][kNumCfgs] = {};
 bool g_attr_done_acc[kMaxDev][kNumCfgs] = {};
+bool g_attr_done_hgn[kMaxDev][kNumHalo] = {};
 
 }  // namespace
 
@@ -1572,9 +1768,7 @@ bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
   if (a.img_rows && (a.img_rows % c.BM != 0 || cfg >= kNumCfgs)) return false;
   if (cfg >= kNumCfgs) {
     if (!halo_ok(a, c)) return false;
-    const int TH = c.BM / a.Wo;
-    const int hb = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
-    if (2 * hb + c.NS * c.BN * 128 + 1024 > 160 * 1024) return false;
+    if (halo_lds_bytes(a, c, false, nullptr) > 160 * 1024) return false;
   }
   return true;
 }
@@ -1607,6 +1801,30 @@ bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg) {
 int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg) {
   const CfgInfo& c = cfg_info(cfg);
   return (a.M / a.gacc.mod) * (a.gacc.rows_img / c.BM);
+}
+
+// dynamic LDS of a halo launch; gn: with the raw-piece staging ring and the {a, b} table of the GN variant
+static int halo_lds_bytes(const GemmArgs& a, const CfgInfo& c, bool gn, int* halo_bytes_out) {
+  const int TH = c.BM / a.Wo;
+  const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
+  int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
+  if (gn) lds += c.nw * (c.NS - 1) * 2048 + (2 * (a.C0 + a.C1) + 64) * 4;
+  lds = (lds + 15) / 16 * 16;
+  if (lds < c.BM * c.BN * 4) lds = c.BM * c.BN * 4;
+  if (halo_bytes_out) *halo_bytes_out = halo_bytes;
+  return lds;
+}
+
+bool sdmi_gemm_hgn_ok(const GemmArgs& a, int cfg) {
+  if (cfg < kNumCfgs || cfg >= kNumCfgs + kNumHalo) return false;
+  const CfgInfo& c = kHaloCfgs[cfg - kNumCfgs];
+  const HaloGn& g = a.hgn;
+  if (!c.hkern_gn || !halo_ok(a, c) || a.accurate || a.ups != 0) return false;
+  const int Cin = a.C0 + a.C1;
+  if (!g.x0 || !g.gamma || !g.beta || !g.rec0 || g.C0 <= 0 || g.C0 % 64 != 0 || g.C1 % 64 != 0 || g.C0 + g.C1 != Cin || (g.C1 > 0 && (!g.x1 || !g.rec1))) return false;
+  if (Cin > 2560 || Cin % 32 != 0 || g.atom <= 0 || (Cin / 32) % g.atom != 0 || g.C0 % g.atom != 0) return false;
+  if (g.T0 <= 0 || (g.P0 != 1 && g.P0 != 2) || (g.C1 > 0 && (g.T1 <= 0 || (g.P1 != 1 && g.P1 != 2)))) return false;
+  return halo_lds_bytes(a, c, true, nullptr) <= 160 * 1024;
 }
 
 bool sdmi_gemm_acc_ok(int cfg) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].kern_acc != nullptr; }
@@ -1753,14 +1971,23 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
     }
     return SDMI_OK;
   };
+  SDMI_REQUIRE(!a.hgn.x0 || halo, "gemm: GroupNorm inside the conv (hgn) needs a halo-reuse config");
   if (halo) {
-    const int TH = c.BM / a.Wo;
-    const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
-    int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
-    if (lds < c.BM * c.BN * 4) lds = c.BM * c.BN * 4;
+    int halo_bytes = 0;
+    const bool gn = a.hgn.x0 != nullptr;
+    if (gn) SDMI_REQUIRE(sdmi_gemm_hgn_ok(a, cfg), "gemm: halo config %s cannot apply GroupNorm to its A operand for this conv", c.name);
+    const int lds = halo_lds_bytes(a, c, gn, &halo_bytes);
     SDMI_REQUIRE(lds <= 160 * 1024, "gemm: halo config %s needs %d B of LDS", c.name, lds);
-    if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
-    hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+    if (gn) {
+      if (!g_attr_done_hgn[dev][cfg - kNumCfgs]) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.hkern_gn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_done_hgn[dev][cfg - kNumCfgs] = true;
+      }
+      hipLaunchKernelGGL(c.hkern_gn, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+    } else {
+      if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
+      hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+    }
     SDMI_CHECK_HIP(hipGetLastError());
   } else if (a.accurate) {
     SDMI_REQUIRE(c.kern_acc != nullptr, "gemm: config %s was not built with the wide A operand (accurate mode)", c.name);

@@ -388,15 +388,21 @@ def accurate_models():
 
 def test_accurate_mode_stress_full_unet_vs_golden(accurate_models):
     """one UNet forward, stress law, 64x64, t = 980 against the reference's own Diffusion.forward: the default mode measures
-    1.40e-3 rel-L2 (activations in fp16); with wide activations what is left is the weights' rounding"""
+    1.40e-3 rel-L2 (weights, activations and attention operands in fp16); with wide activations what is left is the weights' rounding"""
     from oracle import ddpm_ref
     ref = torch.from_numpy(H.load_npz("stress.npz")["unet_64_t980"])
     lat = H.seeded((1, 4, 64, 64), 0).repeat(2, 1, 1, 1).to(DEV)
     unet = accurate_models["diffusion"]
     got = unet(lat, H.seeded((2, 77, 768), 1).to(DEV), ddpm_ref.time_embedding(980).to(DEV)).cpu()
     rel = H.rel_l2(got, ref)
-    G.log_metric(test="accurate_stress_unet", rel_l2=rel, max_abs=(got - ref).abs().max().item(), launches=unet.handle().last_launch_count)
-    assert rel < 7e-4, f"rel L2 {rel:.2e}"
+    # the floor of ONE forward with fp16 weights (tests/golden/stress_floor_forward.py: the fp32 oracle with only the weights and the
+    # attention operands rounded): 9.97e-4 -- in a single forward the weights' rounding alone costs what the activations' does
+    # (9.8e-4; all three classes 1.40e-3, what the default mode measures); it is over the LOOP that they part (4.7e-4 against
+    # 1.6e-3 at 20 steps, stress_floor.json).  Measured: 9.80e-4, on that floor.
+    with open(os.path.join(H.GOLDEN, "stress_floor_forward.json")) as f:
+        floor = json.load(f)["runs"]["weights + attention fp16"]["rel_l2"]
+    G.log_metric(test="accurate_stress_unet", rel_l2=rel, floor=floor, max_abs=(got - ref).abs().max().item(), launches=unet.handle().last_launch_count)
+    assert rel < 1.1 * floor, f"rel L2 {rel:.2e} (floor of fp16 weights {floor:.2e})"
 
 
 def test_accurate_mode_stress_e2e_txt2img_20_steps(accurate_models):
