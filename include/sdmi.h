@@ -225,6 +225,14 @@ typedef struct sdmi_gemm_desc {
    * shapes and strides as a0 / a1 / x0 / x1, which are then unused) and multiplied as a hi + lo fp16 pair against the fp16
    * weights.  cfg < 0 picks the mode's own tile and split-K factor; an explicit cfg must be one built with the variant. */
   const float* a0f; const float* a1f; const float* x0f; const float* x1f; int accurate;
+  /* hgn_x0 != NULL (3x3 stride-1 convs on a halo-reuse config built with the variant): the conv's input is
+   * GroupNorm(32)(+SiLU if hgn_silu) of the RAW NHWC tensor(s) hgn_x0 | hgn_x1 (hgn_c0 | hgn_c1 channels, fp32 if hgn_in_f32 else
+   * fp16, dense), normalised inside the launch by the kernel's producer waves -- sd/diffusion.py:173-179,199-205 as one launch.
+   * c0 must be hgn_c0 + hgn_c1 and c1 = 0 (a0 is not read).  Statistics: the records the tensors' producers left (layout as gacc
+   * above: hgn_t0 / hgn_t1 record rows per image, hgn_p0 / hgn_p1 parts, atoms of hgn_atom channels); gamma / beta [c0] fp32. */
+  const void* hgn_x0; const void* hgn_x1; int hgn_in_f32, hgn_c0, hgn_c1;
+  const float* hgn_gamma; const float* hgn_beta; float hgn_eps; int hgn_silu;
+  const float* hgn_rec0; const float* hgn_rec1; int hgn_t0, hgn_t1, hgn_p0, hgn_p1, hgn_atom;
 } sdmi_gemm_desc;
 int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream);
 /* record rows per image (T) and parts of the statistics the launch described by d writes to d->gacc (d->gacc != NULL);

@@ -41,7 +41,11 @@ class GemmDesc(C.Structure):
                 ("ln_guard", C.c_void_p), ("ln_guard_sigma", C.c_float),
                 ("gna_rec", C.c_void_p), ("gna_gamma", C.c_void_p), ("gna_beta", C.c_void_p), ("gna_eps", C.c_float),
                 ("gna_t", C.c_int), ("gna_parts", C.c_int), ("gna_atom", C.c_int), ("gna_rows", C.c_int),
-                ("a0f", C.c_void_p), ("a1f", C.c_void_p), ("x0f", C.c_void_p), ("x1f", C.c_void_p), ("accurate", C.c_int)]
+                ("a0f", C.c_void_p), ("a1f", C.c_void_p), ("x0f", C.c_void_p), ("x1f", C.c_void_p), ("accurate", C.c_int),
+                ("hgn_x0", C.c_void_p), ("hgn_x1", C.c_void_p), ("hgn_in_f32", C.c_int), ("hgn_c0", C.c_int), ("hgn_c1", C.c_int),
+                ("hgn_gamma", C.c_void_p), ("hgn_beta", C.c_void_p), ("hgn_eps", C.c_float), ("hgn_silu", C.c_int),
+                ("hgn_rec0", C.c_void_p), ("hgn_rec1", C.c_void_p), ("hgn_t0", C.c_int), ("hgn_t1", C.c_int), ("hgn_p0", C.c_int),
+                ("hgn_p1", C.c_int), ("hgn_atom", C.c_int)]
 
 
 class B2bDesc(C.Structure):

@@ -652,16 +652,13 @@ int launch_b2b(const B2bArgs& a, hipStream_t st) {
   SDMI_REQUIRE(dev >= 0 && dev < 16, "b2b: device index %d out of range", dev);
   if (!attr_done[dev]) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
-    if constexpr (BM == 32)
-      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)b2b_kernel<Cf, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::kLds));
     attr_done[dev] = true;
   }
-  if constexpr (BM == 32) {       // (the statistics form exists for 32-row tiles only: sdmi_launch_b2b)
-    if (a.gacc.rec) {
-      hipLaunchKernelGGL((b2b_kernel<Cf, true>), dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
-      SDMI_CHECK_HIP(hipGetLastError());
-      return SDMI_OK;
-    }
+  if (a.gacc.rec) {
+    hipLaunchKernelGGL((b2b_kernel<Cf, true>), dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return SDMI_OK;
   }
   hipLaunchKernelGGL((b2b_kernel<Cf, false>), dim3(a.M / BM), dim3(Cf::kNT), Cf::kLds, st, a);
   SDMI_CHECK_HIP(hipGetLastError());
@@ -691,13 +688,19 @@ int sdmi_launch_b2b(const B2bArgs& a_in, hipStream_t st, int bm) {
                                  a.ldt >= a.S && a.ldt % 8 == 0),
                "b2b: the three-pass form (q | k | v) needs fp16 outputs, no residual, a V^T target and S %% 32 == 0");
   SDMI_REQUIRE(a.ldo >= a.npass2 * kC - (a.npass2 == 3 ? kC : 0) && a.ldo % 8 == 0, "b2b: output row stride %d", a.ldo);
-  SDMI_REQUIRE(!a.gacc.rec || (a.npass2 == 1 && a.gacc.atom >= 4 && a.gacc.atom <= 16 && a.gacc.atom % 2 == 0 && a.gacc.natoms * a.gacc.atom == kC && a.gacc.natoms <= 32 &&
-                               a.gacc.rows_img % 32 == 0 && a.M % a.gacc.rows_img == 0 && a.gacc.parts == 1 && a.gacc.T == a.gacc.rows_img / 32),
-               "b2b: GroupNorm statistics need the one-pass form, even atoms that tile the 320 columns, whole 32-row tiles per image and T = rows / 32, parts = 1");
-  if (bm == 0) bm = (a.M % 64 != 0 || a.M / 32 <= 256 || (a.npass2 == 3 && a.S % 64 != 0)) ? 32 : 64;
+  if (bm == 0) bm = sdmi_b2b_tile_rows(a);
   if (a.gx && a.S % 64 != 0) bm = 32;
   SDMI_REQUIRE((a.npass2 == 1 && !a.gx) || a.S % bm == 0, "b2b: a %d-row tile would straddle images of %d tokens", bm, a.S);
   SDMI_REQUIRE((bm == 32 || bm == 64) && a.M % bm == 0, "b2b: tile height %d does not divide M=%d", bm, a.M);
-  SDMI_REQUIRE(!a.gacc.rec || bm == 32, "b2b: GroupNorm statistics are taken by the 32-row form only (M=%d)", a.M);
+  // (round 5: the 64-row form takes the statistics too -- 165 registers, no spill -- so the batched multi-prompt mode, whose M
+  // runs in whole rounds of 64-row workgroups, keeps the statistics chain)
+  SDMI_REQUIRE(!a.gacc.rec || (a.npass2 == 1 && a.gacc.atom >= 4 && a.gacc.atom <= 16 && a.gacc.atom % 2 == 0 && a.gacc.natoms * a.gacc.atom == kC && a.gacc.natoms <= 32 &&
+                               a.gacc.rows_img % bm == 0 && a.M % a.gacc.rows_img == 0 && a.gacc.parts == 1 && a.gacc.T == a.gacc.rows_img / bm),
+               "b2b: GroupNorm statistics need the one-pass form, even atoms that tile the 320 columns, whole %d-row tiles per image and T = rows / %d, parts = 1", bm, bm);
   return bm == 32 ? launch_b2b<32>(a, st) : launch_b2b<64>(a, st);
+}
+
+// rows per workgroup sdmi_launch_b2b picks for bm = 0 (the statistics' record rows follow it: GnRec::T = rows per image / this)
+int sdmi_b2b_tile_rows(const B2bArgs& a) {
+  return (a.M % 64 != 0 || a.M / 32 <= 256 || (a.npass2 == 3 && a.S % 64 != 0)) ? 32 : 64;
 }

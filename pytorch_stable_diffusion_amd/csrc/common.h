@@ -169,6 +169,7 @@ struct HaloGn {
   const void* x0; const void* x1; int in_f32; int C0, C1;
   const float* gamma; const float* beta; float eps; int silu;
   const float* rec0; const float* rec1; int T0, T1, P0, P1, atom;
+  int depth;           // set by the launcher: intervals a raw piece is requested ahead of its normalisation (1 .. 4, by the LDS left)
 };
 
 struct GemmArgs {
@@ -270,6 +271,7 @@ struct GemmArgs {
   HaloGn hgn;          // hgn.x0 != nullptr: see HaloGn (halo configs built with the variant only: sdmi_gemm_hgn_ok)
 };
 bool sdmi_gemm_hgn_ok(const GemmArgs& a, int cfg);         // this halo config can normalise its own A operand for this conv (shape, LDS)
+int sdmi_gemm_hgn_depth(const GemmArgs& a, int cfg);       // the request-ahead distance it would run with (HaloGn::depth; 0: no room)
 bool sdmi_gemm_acc_ok(int cfg);                              // this tile config was built with the wide-operand variant
 int sdmi_gemm_pick_acc_cfg(const GemmArgs& a, int* ksplit);  // the accurate mode's tile and split-K factor for a shape (heuristic; slab_bytes = room for slabs)
 // can the one-pass epilogue of tile config `cfg` accumulate the GroupNorm statistics of this GEMM? (gemm.hip)
@@ -311,6 +313,7 @@ struct B2bArgs {
   GnRec gacc;                     // GroupNorm statistics of `out` (npass2 == 1 only; rows_img = pixels per image, mod = M, T = rows_img / 32, parts = 1)
 };
 int sdmi_launch_b2b(const B2bArgs& a, hipStream_t st, int bm = 0);   // bm: 32 / 64 rows per workgroup, 0 = by M
+int sdmi_b2b_tile_rows(const B2bArgs& a);                            // what bm = 0 resolves to
 int sdmi_gemm_num_cfgs();
 const char* sdmi_gemm_cfg_name(int cfg);
 int sdmi_gemm_num_plain_cfgs(void);   // configs [0, n) are igemm_kernel tiles; the rest are halo-reuse conv kernels

@@ -735,8 +735,8 @@ struct Engine {
     if (logging) {
       const int cfg = plan_cfg;
       const bool halo = cfg >= sdmi_gemm_num_plain_cfgs();
-      log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
-                 a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.ksplit, 2.0 * a.M * a.N * a.K,
+      log_launch("%s M=%d N=%d K=%d ks=%d s=%d up=%d cfg=%s%s split=%d flops=%.0f wbytes=%.0f out32=%d res=%d", halo ? "halo" : "igemm", a.M, a.N,
+                 a.K, a.ks, a.stride, a.ups, cfg >= 0 ? sdmi_gemm_cfg_name(cfg) : "heur", a.hgn.x0 ? "+gn" : "", a.ksplit, 2.0 * a.M * a.N * a.K,
                  2.0 * a.N * a.K, a.out_f32, a.res != nullptr);
       if (ks_eff > 1 && !deferred) log_launch("finalize M=%d N=%d K=%d split=%d", a.M, a.N, a.K, a.ksplit);
     }
@@ -913,6 +913,35 @@ struct Engine {
     return SDMI_OK;
   }
 
+  // GroupNorm -> SiLU -> conv3x3 as ONE launch (gemm.hip conv3_halo_kernel<.., GN>, GemmArgs::hgn): taken when the conv's plan is a
+  // halo-reuse tile built with the variant and the raw tensor(s) arrive with their producers' statistics records -- the
+  // normalising launch (gn_apply: one read of the fp32 map + one write of the fp16 one, 7 - 22 us at 32x32 / 64x64) and its
+  // intermediate are gone; the conv's producer waves normalise the pieces of the halo image they stage anyway.
+  // `a` describes the conv on the MATERIALISED normalised tensor (C0 = all channels, C1 = 0: that is also its plan key); on
+  // success a.hgn is filled and the caller must not launch the GroupNorm.  SDMI_HALO_GN=0: never.
+  static bool halo_gn_on() { static const bool on = !(getenv("SDMI_HALO_GN") && atoi(getenv("SDMI_HALO_GN")) == 0); return on; }
+  bool try_halo_gn(GemmArgs& a, const Act& x, const Act* x1, const NormW& w, float eps, int silu) {
+    if (!halo_gn_on() || accurate || pend) return false;
+    if (!x.gok || !x.grec || (x1 && (!x1->gok || !x1->grec))) return false;
+    if (x1 && ((x.f != nullptr) != (x1->f != nullptr))) return false;
+    std::map<ShapeKey, Plan>::iterator it;
+    GemmArgs probe = a;
+    if (plan_of(probe, &it) != SDMI_OK || it->second.cfg < 0) return false;
+    HaloGn g;
+    memset(&g, 0, sizeof(g));
+    g.in_f32 = x.f != nullptr;
+    g.x0 = g.in_f32 ? (const void*)x.f : (const void*)x.h; g.C0 = x.C;
+    if (x1) { g.x1 = g.in_f32 ? (const void*)x1->f : (const void*)x1->h; g.C1 = x1->C; }
+    g.gamma = w.gamma; g.beta = w.beta; g.eps = eps; g.silu = silu;
+    g.rec0 = x.grec; g.T0 = x.gT; g.P0 = x.gparts; g.atom = kGnAtom;
+    if (x1) { g.rec1 = x1->grec; g.T1 = x1->gT; g.P1 = x1->gparts; }
+    probe.hgn = g;
+    probe.zero = zero;
+    if (!sdmi_gemm_hgn_ok(probe, it->second.cfg)) return false;
+    a.hgn = g;
+    return true;
+  }
+
   // ---- blocks -------------------------------------------------------------------------------
   // UNET_ResidualBlock (sd/diffusion.py:145-209).  bias1 = conv_feature.bias + linear_time(silu(time))
   // y_to_gn: the caller guarantees that the next launch on y is a single-source GroupNorm (an attention block follows)
@@ -925,8 +954,14 @@ struct Engine {
       // GroupNorm -> SiLU -> conv_feature (sd/diffusion.py:173-179): the norm writes the normalised fp16 tensor (the virtual
       // concat of x | x1 materialises here), the conv reads it.  (A conv that normalised its own A operand in LDS,
       // conv3_gn_kernel, was built in round 2 and lost to this pair on every 512x512 shape: removed in round 3.)
-      TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
-      GemmArgs a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
+      // (round 5: where the plan is a halo tile and x | x1 carry statistics records, the conv normalises its own operand: try_halo_gn)
+      Act shape0 = x;                          // the conv as planned: on the materialised concat, cin channels
+      shape0.C = cin;
+      GemmArgs a = base_args(shape0, nullptr, r.conv1, x.H, x.W, 1, 0);
+      if (!try_halo_gn(a, x, x1, r.gn1, 1e-5f, 1)) {
+        TRY(groupnorm(x, x1, r.gn1, 1e-5f, 1, &t0));
+        a = base_args(t0, nullptr, r.conv1, x.H, x.W, 1, 0);
+      }
       a.bias = bias1; a.out = h.h; a.ldc = h.C;
       if (accurate) set_out(a, h);             // groupnorm_merged reads the fp32 values
       pend_keep16 = false;                     // h has one reader: groupnorm_merged
@@ -941,8 +976,12 @@ struct Engine {
       s.ldc = sk.C;
       TRY(gemm(s));
     }
-    TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
-    GemmArgs a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+    GemmArgs a = base_args(h, nullptr, r.conv2, x.H, x.W, 1, 0);
+    // (blocks with a fused skip segment run the generic kernel, which re-stages its A tile per tap: they keep the GroupNorm launch)
+    if ((r.has_skip && r.w2s) || !try_halo_gn(a, h, nullptr, r.gn2, 1e-5f, 1)) {
+      TRY(groupnorm(h, nullptr, r.gn2, 1e-5f, 1, &t1));
+      a = base_args(t1, nullptr, r.conv2, x.H, x.W, 1, 0);
+    }
     if (r.has_skip && r.w2s) {                 // the 1x1 skip conv as an extra K-range of conv_merged (sd/diffusion.py:143,209)
       a.x0 = x.h; a.x0f = x.f; a.X0 = x.C;
       if (x1) { a.x1 = x1->h; a.x1f = x1->f; a.X1 = x1->C; }
@@ -999,10 +1038,10 @@ struct Engine {
     if (y.f) { t.out = y.f; t.out_f32 = 1; t.out16 = y.h; } else { t.out = y.h; }
     t.M = a1.M(); t.eps = 1e-5f; t.npass2 = 1; t.ldo = 320;
     t.ln_guard = ln_guard; t.ln_guard_thr2 = ln_guard_thr() * ln_guard_thr();
-    if (y_gacc && y_gacc->grec && (a1.H * a1.W) % 64 == 0 && t.M / 32 <= 256 &&      // (32-row tiles only: the 64-row form has no registers to spare)
-        (a1.H * a1.W) / 32 * (320 / kGnAtom) <= kGnRecMax) {
+    const int bm = sdmi_b2b_tile_rows(t);                  // 32 rows per workgroup up to one round of workgroups, else 64
+    if (y_gacc && y_gacc->grec && (a1.H * a1.W) % 64 == 0 && (a1.H * a1.W) / bm * (320 / kGnAtom) <= kGnRecMax) {
       t.gacc.rec = y_gacc->grec; t.gacc.atom = kGnAtom; t.gacc.natoms = 320 / kGnAtom; t.gacc.rows_img = a1.H * a1.W; t.gacc.mod = t.M;
-      t.gacc.T = t.gacc.rows_img / 32; t.gacc.parts = 1;
+      t.gacc.T = t.gacc.rows_img / bm; t.gacc.parts = 1;
       y_gacc->gok = true; y_gacc->gT = t.gacc.T; y_gacc->gparts = 1;
     }
     const double flops = 2.0 * t.M * 320.0 * (320.0 + K2);

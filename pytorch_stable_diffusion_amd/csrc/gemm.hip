@@ -111,7 +111,15 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
   // GroupNorm statistics of the stored values (GnRec, common.h): with NT a multiple of the BN/8 column chunks of a row, a thread
   // keeps the SAME 8 columns in every item, so it accumulates their moments in four registers (the two atoms they fall into)
   constexpr bool GACC = (NT % (BN / 8) == 0) && (BN % 64 == 0);
+  // 160-wide tiles (round 5): NT is no multiple of the 20 column chunks of a row, so a thread's items wander over the columns and
+  // cannot keep per-column registers.  They write the values they store back into the fp32 tile instead; afterwards one thread per
+  // COLUMN adds its 128 (64) rows up in row order and one thread per 10-channel atom its columns: a tile holds whole atoms
+  // (160 = 16 x 10, n0 a multiple of 160), so every record is {moments, 0}.  ~1 us per launch where taken; it keeps the
+  // statistics chain (and with it the one-pass GroupNorm / the GroupNorm inside the halo conv) alive behind the 160-wide
+  // plans the batched multi-prompt mode is tuned to.
+  constexpr bool GACC160 = !GACC && BN == 160;
   const bool gstat = GACC && p.gacc.rec != nullptr;      // workgroup-uniform
+  const bool gstat160 = GACC160 && p.gacc.rec != nullptr;
   GaccThread<(NT < 1024)> gth;
   int g_split = 8;
   if (gstat) {
@@ -241,6 +249,16 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
           for (int e = 0; e < 8; ++e) x[e] = p.out_f32 ? v[e] : (float)o16[e];
           if (!(SDMI_GACC_ABLATE & 4)) gth.add(x, g_split);
         }
+        if constexpr (GACC160) {
+          if (gstat160) {  // the same values back into the tile (this thread's own item: nobody else reads or writes these 32 bytes)
+            float* cw = const_cast<float*>(Cs) + row * BN + c8 * 8;
+            f32x4 w0, w1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w0[e] = p.out_f32 ? v[e] : (float)o16[e]; w1[e] = p.out_f32 ? v[4 + e] : (float)o16[4 + e]; }
+            *(f32x4*)cw = w0;
+            *(f32x4*)(cw + 4) = w1;
+          }
+        }
       }
       if (p.rowstat && ((BN / 8) & (BN / 8 - 1)) == 0) {   // wave-uniform branch; the BN/8 lanes of one row are consecutive and aligned (power-of-two tiles only)
 #pragma unroll
@@ -249,6 +267,36 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, const float* Cs, i
       }
     }
     }   // chunk
+    if constexpr (GACC160) {
+      if (gstat160) {
+        float* s_g = const_cast<float*>(Cs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every item of the tile has been rewritten
+        float cs_ = 0.f, cq_ = 0.f;
+        if (tid < BN) {
+#pragma unroll 8
+          for (int rr = 0; rr < BM; ++rr) { const float x = s_g[rr * BN + tid]; cs_ += x; cq_ = fmaf(x, x, cq_); }
+        }
+        __builtin_amdgcn_s_barrier();                      // the column sums are in registers: the tile may be overwritten
+        if (tid < BN) *(f32x2*)(s_g + 2 * tid) = f32x2{cs_, cq_};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int atom = p.gacc.atom, na = BN / atom;      // launcher: BN % atom == 0, n0 % atom == 0
+        if (tid < na && n0 + tid * atom < p.N) {
+          float s1 = 0.f, s2 = 0.f;
+          for (int k = 0; k < atom; ++k) { const f32x2 t = *(const f32x2*)(s_g + 2 * (tid * atom + k)); s1 += t[0]; s2 += t[1]; }
+          const bool phased = p.gacc.mod != p.M;
+          const int ph = phased ? m0 / p.gacc.mod : 0;
+          const int mm = m0 - ph * p.gacc.mod;
+          const int img = gnrec_div_rows(p.gacc, mm);
+          const int t_row = ph * (p.gacc.rows_img / BM) + (mm - img * p.gacc.rows_img) / BM;
+          const int at = gnrec_div_atom(p.gacc, n0) + tid;
+          f32x2* r = (f32x2*)p.gacc.rec + ((size_t)(img * p.gacc.T + t_row) * p.gacc.natoms + at) * 2;
+          r[0] = f32x2{s1, s2};
+          r[1] = f32x2{0.f, 0.f};
+        }
+      }
+    }
     if constexpr (GACC) {
       if (gstat && !(SDMI_GACC_ABLATE & 1)) {
         // fixed-order reduction inside the workgroup: lanes of a wave that hold the same column chunk (butterfly), one record
@@ -1013,19 +1061,24 @@ struct HCfg {
 //   * prologue (all waves): the statistics records the producers of x0 / x1 left (GnRec) are summed to mean / rstd per group in
 //     fp64, as gn_apply_kernel of norm.hip sums them, and folded with gamma / beta into a per-channel {a, b} table in LDS
 //     (y = a x + b), all C0 + C1 channels of this tile's image;
-//   * first chunk: the producer waves load their halo pieces to registers, normalise, write the fp16 image;
-//   * steady state: the RAW piece of chunk c+1 goes to a small per-wave staging ring by LDS-DMA (fp32: two 1 KiB instructions,
-//     fp16: one + a dummy, so the counted vmcnt of the weight ring keeps a constant group size) and is normalised LDS -> LDS
-//     NS-2 intervals later, when the ring's counted wait has covered it -- each lane rewrites the 16 bytes it fetched itself, so
-//     no extra barrier; border pixels stay zero (the conv pads the NORMALISED tensor).
+//   * a THIRD group of NW waves ("normalisers", GN only: 192 NW threads per workgroup) owns the halo image: the first chunk's
+//     pieces go through registers; in the steady state the RAW piece of chunk c+1 goes to a two-slot staging area per wave by
+//     LDS-DMA (fp32: two 1 KiB instructions, fp16: one) and is normalised LDS -> LDS one interval later, while the next piece's
+//     DMA flies -- each lane rewrites the 16 bytes it fetched itself, so no extra barrier; border pixels stay zero (the conv pads
+//     the NORMALISED tensor).  The weight-ring producer waves keep only their weight tiles (one DMA fewer per interval than in
+//     the plain kernel, whose K loop is paced by their DMA issue: two forms that gave the normalisation to THEM -- behind the
+//     ring's counted wait, or one interval later in front of it -- cost the 64x64 convs 19 - 25 us each, more than the
+//     GroupNorm launch they replaced).
 // The halo image, the fragment reads and the MFMA loop are the plain kernel's: same sums in the same order on the same fp16
 // values gn_apply_kernel would have written.
-template <class C, bool GN = false>
-__global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_bytes) {
+// F32: the raw tensors are fp32 (the residual stream: two DMA instructions per raw piece) or fp16 (conv_feature's output: one).
+template <class C, bool GN = false, bool F32 = true>
+__global__ __launch_bounds__(GN ? C::NT + 64 * C::NW : C::NT) void conv3_halo_kernel(GemmArgs p, int halo_bytes) {
   sdmi_kernarg_warm<sizeof(GemmArgs) + 24>();     // + halo_bytes + the hidden grid size (gridDim.x)
-  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = C::NT, NS = C::NS;
-  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = C::G + (GN ? 1 : 0), NTAPH = C::NTAPH;      // GN: two raw-piece DMAs per interval
-  constexpr int GD = NS - 2, GSLOTS = GD + 1;      // GN: intervals between a raw piece's DMA and its normalisation; staging slots per wave
+  constexpr int BM = C::BM, BN = C::BN, NW = C::NW, NT = GN ? C::NT + 64 * C::NW : C::NT, NS = C::NS;
+  constexpr int FM = C::FM, FN = C::FN, RB = C::RB, G = GN ? RB : C::G, NTAPH = C::NTAPH;      // GN: the weight producers issue no halo DMA
+  constexpr int NR = F32 ? 2 : 1;                  // GN: raw-piece DMA instructions per interval and normaliser wave
+  const int gd = GN ? p.hgn.depth : 0, gslots = gd + 1;   // GN: request-ahead distance of the raw pieces (intervals), staging slots per wave
 #ifdef SDMI_CLK_PROBE
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long clk_setup = 0;
@@ -1033,7 +1086,8 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave_id >= NW;
+  const bool producer = wave_id >= NW;                 // weight-ring producers AND (GN) normalisers: everybody but the MFMA waves
+  const bool normaliser = GN && wave_id >= 2 * NW;
   const int wave = wave_id % NW;
   const int wm = wave / C::WN, wn = wave % C::WN;
 
@@ -1072,7 +1126,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
   char* dump = bring + NS * C::B_BYTES;
   // GN: [dump 1 KiB][staging: NW waves x GSLOTS x 2 KiB][table: {a, b} per channel][mean | rstd: 64 floats]
   char* const gstage = dump + 1024;
-  float* const gtab = (float*)(gstage + NW * GSLOTS * 2048);
+  float* const gtab = (float*)(gstage + NW * gslots * 2048);
   if constexpr (GN) {
     const HaloGn& g = p.hgn;
     const int cpg = Cin >> 5, apg = cpg / g.atom, na0 = g.C0 / g.atom, na1 = g.C1 / g.atom;
@@ -1151,48 +1205,54 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
     // ---- halo pieces owned by this wave: piece q = tau*NW + wave covers 8 consecutive interior pixels ----
     const int rowp = W >> 3;                          // pieces per image row
     const int NHI = (TH + 2) * rowp;                  // pieces per chunk (<= NTAPH * NW, checked by the launcher)
-    int h_pix[NTAPH], h_gch[NTAPH], h_lds[NTAPH];
-    bool h_in[NTAPH];
-#pragma unroll
-    for (int t = 0; t < NTAPH; ++t) {
+    // A piece's descriptor is COMPUTED when the piece is requested (~20 integer instructions), not kept in per-tap register arrays
+    // indexed through an unrolled `if (tt == tap)` chain (round 5): that chain was eight copies of the request code and an
+    // eight-way branch in front of every request -- the in-kernel stamps put the producers' DMA-issue phase at 720 cycles per
+    // interval for FIVE instructions (the four weight pieces alone: 210), on the role that paces the K loop.
+    const int rp_magic = (65536 + rowp - 1) / rowp;   // q / rowp == (q * rp_magic) >> 16 for q < 64, rowp <= 8
+    struct Piece { int pix, gch, lds; bool in; };
+    auto piece_of = [&](int t) {
       const int q = t * NW + wave;
-      const int hy = q / rowp, seg = q - hy * rowp;
+      const int hy = (q * rp_magic) >> 16, seg = q - hy * rowp;
       const int hx = 1 + seg * 8 + (lane >> 3);       // interior columns 1..W
       const int hp = hy * W2 + hx;
       const int y = y0 - 1 + hy, x = hx - 1;
-      h_in[t] = q < NHI && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;
-      h_pix[t] = img * p.Hs * p.Ws + (y >> p.ups) * p.Ws + (x >> p.ups);
-      h_gch[t] = ((lane & 7) ^ ((hp >> 1) & 7)) * 8;
-      h_lds[t] = q < NHI ? (hy * W2 + 1 + seg * 8) * 128 : -1;   // wave-uniform LDS byte offset of the piece
-    }
+      Piece d;
+      d.in = q < NHI && (unsigned)y < (unsigned)Hi && (unsigned)x < (unsigned)Wi;
+      d.pix = img * p.Hs * p.Ws + (y >> p.ups) * p.Ws + (x >> p.ups);
+      d.gch = ((lane & 7) ^ ((hp >> 1) & 7)) * 8;
+      d.lds = q < NHI ? (hy * W2 + 1 + seg * 8) * 128 : -1;      // wave-uniform LDS byte offset of the piece
+      return d;
+    };
     auto halo_piece = [&](int t, int chunk, char* hb) {
+      const Piece d = piece_of(t);
       const int cabs = chunk << 6;
       const bool second = cabs >= p.C0;
       const f16* base = second ? p.a1 : p.a0;
       const int ld = second ? p.lda1 : p.lda0;
       const int cc = second ? cabs - p.C0 : cabs;
-      const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
-      const f16* gz = p.zero + h_gch[t];
-      const f16* g = h_in[t] ? base + ((size_t)h_pix[t] * ld + cc + h_gch[t]) : gz;
+      const int lds_off = __builtin_amdgcn_readfirstlane(d.lds);
+      const f16* gz = p.zero + d.gch;
+      const f16* g = d.in ? base + ((size_t)d.pix * ld + cc + d.gch) : gz;
       glds16(lds_off >= 0 ? g : gz, lds_off >= 0 ? hb + lds_off : dump);
     };
     // ---- GN: raw piece -> normalised fp16 piece ----
     // byte address of this lane's 8 raw channels of piece t in chunk `chunk` (nullptr: border pixel / no such piece)
-    auto raw_src = [&](int t, int chunk) -> const char* {
+    auto raw_src = [&](const Piece& d, int chunk) -> const char* {
       const int cabs = chunk << 6;
       const bool second = cabs >= p.hgn.C0;
       const char* base = (const char*)(second ? p.hgn.x1 : p.hgn.x0);
       const int ld = second ? p.hgn.C1 : p.hgn.C0;
       const int cc = second ? cabs - p.hgn.C0 : cabs;
-      const size_t el = (size_t)h_pix[t] * ld + cc + h_gch[t];
-      return (h_in[t] && h_lds[t] >= 0) ? base + el * (p.hgn.in_f32 ? 4 : 2) : nullptr;
+      const size_t el = (size_t)d.pix * ld + cc + d.gch;
+      return (d.in && d.lds >= 0) ? base + el * (F32 ? 4 : 2) : nullptr;
     };
     // y = SiLU(a x + b) of the lane's 8 channels (table entries of concat channels chunk*64 + gch ..), zero outside the image,
     // written where the LDS-DMA of the plain kernel would have put the lane's 16 bytes
-    auto norm_store = [&](int t, int chunk, char* hb, const float (&x)[8]) {
-      const int lds_off = __builtin_amdgcn_readfirstlane(h_lds[t]);
+    auto norm_store = [&](const Piece& d, int chunk, char* hb, const float (&x)[8]) {
+      const int lds_off = __builtin_amdgcn_readfirstlane(d.lds);
       if (lds_off < 0) return;
-      const float* tp = gtab + 2 * ((chunk << 6) + h_gch[t]);
+      const float* tp = gtab + 2 * ((chunk << 6) + d.gch);
       f32x4 tv[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) tv[k] = *(const f32x4*)(tp + 4 * k);          // {a0 b0 a1 b1} ...
@@ -1201,27 +1261,22 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       for (int e = 0; e < 8; ++e) {
         float y = fmaf(x[e], tv[e >> 1][2 * (e & 1)], tv[e >> 1][2 * (e & 1) + 1]);
         if (p.hgn.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));
-        o[e] = h_in[t] ? (f16)y : (f16)0.f;
+        o[e] = d.in ? (f16)y : (f16)0.f;
       }
       *(f16x8*)(hb + lds_off + lane * 16) = o;
     };
-    char* const my_stage = gstage + wave * (GSLOTS * 2048);
-    auto raw_dma = [&](int t, int chunk, int slot) {      // two LDS-DMA instructions, always (constant group size for the counted waits)
-      const char* src = raw_src(t, chunk);
+    char* const my_stage = gstage + wave * (gslots * 2048);
+    auto raw_dma = [&](int t, int chunk, int slot) {      // NR LDS-DMA instructions, always (constant group size for the counted waits)
+      const char* src = raw_src(piece_of(t), chunk);
       char* sl = my_stage + slot * 2048;
       const char* z = (const char*)p.zero + (lane & 7) * 16;
-      if (p.hgn.in_f32) {
-        glds16(src ? src : z, sl);
-        glds16(src ? src + 16 : z, sl + 1024);
-      } else {
-        glds16(src ? src : z, sl);
-        glds16(z, dump);
-      }
+      glds16(src ? src : z, sl);
+      if constexpr (F32) glds16(src ? src + 16 : z, sl + 1024);
     };
     auto norm_from_stage = [&](int t, int chunk, char* hb, int slot) {
       const char* sl = my_stage + slot * 2048 + lane * 16;
       float x[8];
-      if (p.hgn.in_f32) {
+      if constexpr (F32) {
         const f32x4 u0 = *(const f32x4*)sl, u1 = *(const f32x4*)(sl + 1024);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = u0[e]; x[4 + e] = u1[e]; }
@@ -1230,7 +1285,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (float)u[e];
       }
-      norm_store(t, chunk, hb, x);
+      norm_store(piece_of(t), chunk, hb, x);
     };
     // ---- weight tile pointers: w[n][tap*Cin + chunk*64 + ...] ----
     const f16* b_ptr[RB];
@@ -1254,48 +1309,116 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       }
       if (++tap == 9) { tap = 0; ++chunk; }
     };
-    // prologue: whole halo of the first chunk + first NS-1 weight tiles
-    if constexpr (GN) {
-      // the first chunk's pieces through registers (all of this wave's loads in flight at once), the weight tiles behind them
-      f32x4 r0[NTAPH], r1[NTAPH];
+    // GN: the first chunk's pieces go through registers (all of a wave's loads in flight at once, then converted); the normaliser
+    // wave q takes the even pieces and the weight producer wave q the odd ones, so the set-up is half as long as with one role.
+    auto first_chunk = [&](auto PAR) {
+      constexpr int par = decltype(PAR)::value, NH = (NTAPH + 1 - par) / 2;
+      f32x4 r0[NH > 0 ? NH : 1], r1[NH > 0 ? NH : 1];
 #pragma unroll
-      for (int t = 0; t < NTAPH; ++t) {
-        const char* src = raw_src(t, c_first);
-        r0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; r1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < NH; ++k) {
+        const char* src = raw_src(piece_of(2 * k + par), c_first);
+        r0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; r1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (src) {
-          r0[t] = *(const f32x4*)src;
-          if (p.hgn.in_f32) r1[t] = *(const f32x4*)(src + 16);
+          r0[k] = *(const f32x4*)src;
+          if constexpr (F32) r1[k] = *(const f32x4*)(src + 16);
         }
       }
 #pragma unroll
-      for (int s2 = 0; s2 < NS - 1; ++s2)
-        if (s2 < nk) stage_b(s2);
-#pragma unroll
-      for (int t = 0; t < NTAPH; ++t) {
+      for (int k = 0; k < NH; ++k) {
         float x[8];
-        if (p.hgn.in_f32) {
+        if constexpr (F32) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { x[e] = r0[t][e]; x[4 + e] = r1[t][e]; }
+          for (int e = 0; e < 4; ++e) { x[e] = r0[k][e]; x[4 + e] = r1[k][e]; }
         } else {
-          const f16x8 u = __builtin_bit_cast(f16x8, r0[t]);
+          const f16x8 u = __builtin_bit_cast(f16x8, r0[k]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = (float)u[e];
         }
-        norm_store(t, c_first, hb0, x);
+        norm_store(piece_of(2 * k + par), c_first, hb0, x);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    if (normaliser) {
+      // ================= GN: the normaliser waves own the halo image =================
+      if constexpr (GN) {
+        first_chunk(std::integral_constant<int, 0>{});    // the even pieces of the first chunk (the weight producers take the odd ones)
+        // The raw piece that is normalised in interval u (tap k = u % 9 < NTAPH of chunk c: piece k of chunk c+1) is requested gd
+        // intervals earlier -- the tensors were just written by another kernel, a piece takes 1 - 2 us to arrive from the other
+        // XCDs' L2 / the Infinity Cache, two to four intervals of this loop (a first form that gave it ONE interval waited for it
+        // every time: +17 us per 64x64 conv).  EVERY interval requests exactly NR instructions (a dummy when there is no piece),
+        // so "piece of interval u has landed" is the constant count vmcnt(gd x NR).
+        int itap = 0, ichunk = c_first;                 // (chunk, tap) of the interval whose piece is REQUESTED next
+        auto request = [&](int u) {
+          const bool real = itap < NTAPH && (ichunk + 1) * 9 < kt1 && u < nk;
+          if (real) {
+            raw_dma(itap, ichunk + 1, u % gslots);
+          } else {
+            glds16(p.zero, dump);
+            if constexpr (F32) glds16(p.zero, dump);
+          }
+          if (++itap == 9) { itap = 0; ++ichunk; }
+        };
+        for (int u = 0; u < gd; ++u) request(u);        // the pieces of the first gd intervals, behind the first chunk's own loads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int ctap = 0, cchunk = c_first;                 // (chunk, tap) being CONSUMED in interval t
+#ifdef SDMI_CLK_PROBE_FINE
+        unsigned long long n_req = 0, n_vm = 0, n_cv = 0, n_bar = 0;
+#endif
+        for (int t = 0; t < nk; ++t) {
+#ifdef SDMI_CLK_PROBE_FINE
+          const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
+          request(t + gd);
+#ifdef SDMI_CLK_PROBE_FINE
+          const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+#endif
+          switch (gd * NR) {                            // all but the newest gd x NR instructions have landed: interval t's piece is there
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          }
+#ifdef SDMI_CLK_PROBE_FINE
+          const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+#endif
+          if (ctap < NTAPH && (cchunk + 1) * 9 < kt1) {
+            char* const hbn = ((cchunk + 1 - c_first) & 1) ? hb1 : hb0;
+            norm_from_stage(ctap, cchunk + 1, hbn, t % gslots);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SDMI_CLK_PROBE_FINE
+          const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+#endif
+          __builtin_amdgcn_s_barrier();
+#ifdef SDMI_CLK_PROBE_FINE
+          n_req += q1 - q0; n_vm += q2 - q1; n_cv += q3 - q2; n_bar += __builtin_amdgcn_s_memtime() - q3;
+#endif
+          if (++ctap == 9) { ctap = 0; ++cchunk; }
+        }
+#ifdef SDMI_CLK_PROBE_FINE
+        if (lane == 0 && wave == 0 && blockIdx.x < 512) {
+          g_clk_pre[blockIdx.x][0] = n_req; g_clk_pre[blockIdx.x][1] = n_vm; g_clk_pre[blockIdx.x][2] = n_cv; g_clk_pre[blockIdx.x][3] = n_bar;
+        }
+#endif
+      }
     } else {
+    // ================= weight-ring producers (plain kernel: they also request the halo pieces) =================
+    // prologue: whole halo of the first chunk + first NS-1 weight tiles
+    if constexpr (!GN) {
 #pragma unroll
-    for (int t = 0; t < NTAPH; ++t) halo_piece(t, c_first, hb0);
+      for (int t = 0; t < NTAPH; ++t) halo_piece(t, c_first, hb0);
+    }
 #pragma unroll
     for (int s2 = 0; s2 < NS - 1; ++s2)
       if (s2 < nk) stage_b(s2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if constexpr (GN) first_chunk(std::integral_constant<int, 1>{});      // behind the weight tiles' requests
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int nxt = NS - 1;
     int ctap = 0, cchunk = c_first;                   // (chunk, tap) being CONSUMED in interval t
-    int gslot = 0, dslot = 0, dtap = 0, dchunk = c_first;   // GN: staging slot of interval t; slot / (chunk, tap) of interval t - GD
 #ifdef SDMI_CLK_PROBE_FINE
     unsigned long long acc_issue = 0, acc_vm = 0, acc_bar = 0;
 #endif
@@ -1305,18 +1428,14 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #endif
       if (t + NS - 1 < nk) {
         stage_b(nxt);
-        // one halo piece of the NEXT chunk (dummy DMA keeps the per-interval count constant)
-        const bool have_next = (cchunk + 1) * 9 < kt1;
-        if (ctap < NTAPH && have_next) {
-#pragma unroll
-          for (int tt = 0; tt < NTAPH; ++tt)
-            if (tt == ctap) {
-              if constexpr (GN) raw_dma(tt, cchunk + 1, gslot);
-              else halo_piece(tt, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
-            }
-        } else {
-          glds16(p.zero, dump);
-          if constexpr (GN) glds16(p.zero, dump);
+        if constexpr (!GN) {
+          // one halo piece of the NEXT chunk (dummy DMA keeps the per-interval count constant)
+          const bool have_next = (cchunk + 1) * 9 < kt1;
+          if (ctap < NTAPH && have_next) {
+            halo_piece(ctap, cchunk + 1, ((cchunk + 1 - c_first) & 1) ? hb1 : hb0);
+          } else {
+            glds16(p.zero, dump);
+          }
         }
       }
 #ifdef SDMI_CLK_PROBE_FINE
@@ -1329,22 +1448,6 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
 #ifdef SDMI_CLK_PROBE_FINE
       const unsigned long long s2 = __builtin_amdgcn_s_memtime();
 #endif
-      if constexpr (GN) {
-        // the raw piece requested GD intervals ago is covered by the wait above (vmcnt(GD x G) leaves only younger groups in
-        // flight, and the tail's waits are stricter): normalise it into the next chunk's image.  Pieces are requested in taps
-        // 0 .. NTAPH-1 = 8-GD of a chunk, so the last one is written in tap 8, behind the barrier that ends the chunk.
-        if (t >= GD && dtap < NTAPH && (dchunk + 1) * 9 < kt1) {
-#pragma unroll
-          for (int tt = 0; tt < NTAPH; ++tt)
-            if (tt == dtap) norm_from_stage(tt, dchunk + 1, ((dchunk + 1 - c_first) & 1) ? hb1 : hb0, dslot);
-        }
-        if (t >= GD) {
-          if (++dtap == 9) { dtap = 0; ++dchunk; }
-          dslot = (dslot + 1 == GSLOTS) ? 0 : dslot + 1;
-        }
-        gslot = (gslot + 1 == GSLOTS) ? 0 : gslot + 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
       __builtin_amdgcn_s_barrier();
 #ifdef SDMI_CLK_PROBE_FINE
       acc_issue += s1 - s0; acc_vm += s2 - s1; acc_bar += __builtin_amdgcn_s_memtime() - s2;
@@ -1358,6 +1461,7 @@ __global__ __launch_bounds__(C::NT) void conv3_halo_kernel(GemmArgs p, int halo_
       g_clk_probe[1024 + blockIdx.x][0] = acc_bar;
     }
 #endif
+    }   // weight-ring producers
   } else {
     // ---- consumers: zero the padding columns of both halo buffers once, then MFMA ----
     for (int i = tid; i < (TH + 2) * 2 * 8 * 2; i += NW * 64) {       // (row, side, 16-B chunk, buffer)
@@ -1642,7 +1746,8 @@ struct CfgInfo {
   void (*kern_gna)(GemmArgs);     // the same tile with GroupNorm on the A fragments (GemmArgs::gna_rec), or nullptr
   void (*kern_acc)(GemmArgs);     // the same tile with the fp32 A operand as a hi + lo fp16 pair (GemmArgs::accurate), or nullptr
   int LDS_acc;
-  void (*hkern_gn)(GemmArgs, int); // halo kernel that normalises its own A operand (GemmArgs::hgn), or nullptr
+  void (*hkern_gn)(GemmArgs, int); // halo kernel that normalises its own A operand (GemmArgs::hgn) from fp32 tensors, or nullptr
+  void (*hkern_gn16)(GemmArgs, int); // ... from fp16 tensors
 };
 
 #define CFG_ENTRY(BM, BN, WM, WN, NS) \
@@ -1711,15 +1816,16 @@ const CfgInfo kCfgs[] = {
 };
 #define CFG_ENTRY_H(BM, BN, WM, WN, NS) \
   {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
-   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, nullptr}
+   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, nullptr, nullptr}
 // ("N": also built with GroupNorm(+SiLU) applied to its own A operand, GemmArgs::hgn -- the tiles the 64x64 / 32x32 / 16x16
 // convs of a step are planned with)
 #define CFG_ENTRY_HN(BM, BN, WM, WN, NS) \
   {"h" #BM "x" #BN "s" #NS, BM, BN, NS, HCfg<BM, BN, WM, WN, NS>::NT, 0, nullptr, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>>, \
-   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>, true>}
+   HCfg<BM, BN, WM, WN, NS>::NTAPH, HCfg<BM, BN, WM, WN, NS>::NW, nullptr, nullptr, 0, conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>, true, true>, \
+   conv3_halo_kernel<HCfg<BM, BN, WM, WN, NS>, true, false>}
 const CfgInfo kHaloCfgs[] = {
     CFG_ENTRY_HN(128, 128, 2, 2, 3), CFG_ENTRY_H(128, 64, 2, 2, 3), CFG_ENTRY_H(64, 64, 2, 2, 3), CFG_ENTRY_H(64, 128, 2, 2, 3),
-    CFG_ENTRY_HN(256, 128, 4, 2, 3), CFG_ENTRY_HN(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
+    CFG_ENTRY_H(256, 128, 4, 2, 3), CFG_ENTRY_HN(128, 128, 2, 2, 4), CFG_ENTRY_H(256, 64, 4, 2, 3),
     CFG_ENTRY_HN(128, 160, 4, 1, 3),
 };
 constexpr int kNumHalo = sizeof(kHaloCfgs) / sizeof(kHaloCfgs[0]);
@@ -1728,7 +1834,7 @@ constexpr int kMaxDev = 16;
 bool g_attr_done[kMaxDev][kNumCfgs + kNumHalo] = {};   // hipFuncSetAttribute is per device
 bool g_attr_done_gna[kMaxDev][kNumCfgs] = {};
 bool g_attr_done_acc[kMaxDev][kNumCfgs] = {};
-bool g_attr_done_hgn[kMaxDev][kNumHalo] = {};
+bool g_attr_done_hgn[kMaxDev][kNumHalo][2] = {};
 
 }  // namespace
 
@@ -1757,6 +1863,18 @@ static bool halo_ok(const GemmArgs& a, const CfgInfo& c) {
   const int TH = c.BM / a.Wo;
   if ((TH + 2) * (a.Wo / 8) > c.ntaph * c.nw) return false;      // one halo piece per producer wave per tap
   return true;
+}
+
+// dynamic LDS of a halo launch; gn: with the raw-piece staging ring and the {a, b} table of the GN variant
+static int halo_lds_bytes(const GemmArgs& a, const CfgInfo& c, bool gn, int* halo_bytes_out) {
+  const int TH = c.BM / a.Wo;
+  const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
+  int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
+  if (gn) lds += c.nw * (a.hgn.depth + 1) * 2048 + (2 * (a.C0 + a.C1) + 64) * 4;   // depth + 1 raw-piece staging slots per normaliser wave + the {a, b} table
+  lds = (lds + 15) / 16 * 16;
+  if (lds < c.BM * c.BN * 4) lds = c.BM * c.BN * 4;
+  if (halo_bytes_out) *halo_bytes_out = halo_bytes;
+  return lds;
 }
 
 bool sdmi_gemm_cfg_applicable(const GemmArgs& a, int cfg) {
@@ -1794,7 +1912,9 @@ bool sdmi_gemm_gacc_ok(const GemmArgs& a, int cfg) {
   if (cfg < 0 || cfg >= sdmi_gemm_num_cfgs()) return false;
   const CfgInfo& c = cfg_info(cfg);
   if (a.outT || !gacc_atom_ok(a.gacc.atom) || a.gacc.natoms * a.gacc.atom != a.N || a.gacc.rows_img <= 0) return false;
-  if (c.BN % 64 != 0 || c.NT % (c.BN / 8) != 0 || c.BN / a.gacc.atom + 2 > c.NT) return false;   // one lane per atom of a tile
+  if (c.BN == 160) {                                        // (store_tile GACC160: whole atoms per tile, column sums from the tile)
+    if (160 % a.gacc.atom != 0 || a.N % 160 != 0 || a.M % c.BM != 0) return false;
+  } else if (c.BN % 64 != 0 || c.NT % (c.BN / 8) != 0 || c.BN / a.gacc.atom + 2 > c.NT) return false;   // one lane per atom of a tile
   if (a.gacc.rows_img % c.BM != 0 || a.gacc.mod % a.gacc.rows_img != 0 || a.M % a.gacc.mod != 0) return false;
   return (long)sdmi_gemm_gacc_T(a, cfg) * a.gacc.natoms * 2 <= kGaccMaxRec;
 }
@@ -1803,28 +1923,29 @@ int sdmi_gemm_gacc_T(const GemmArgs& a, int cfg) {
   return (a.M / a.gacc.mod) * (a.gacc.rows_img / c.BM);
 }
 
-// dynamic LDS of a halo launch; gn: with the raw-piece staging ring and the {a, b} table of the GN variant
-static int halo_lds_bytes(const GemmArgs& a, const CfgInfo& c, bool gn, int* halo_bytes_out) {
-  const int TH = c.BM / a.Wo;
-  const int halo_bytes = (((TH + 2) * (a.Wo + 2) * 128) + 1023) / 1024 * 1024;
-  int lds = 2 * halo_bytes + c.NS * c.BN * 128 + 1024;
-  if (gn) lds += c.nw * (c.NS - 1) * 2048 + (2 * (a.C0 + a.C1) + 64) * 4;
-  lds = (lds + 15) / 16 * 16;
-  if (lds < c.BM * c.BN * 4) lds = c.BM * c.BN * 4;
-  if (halo_bytes_out) *halo_bytes_out = halo_bytes;
-  return lds;
-}
-
 bool sdmi_gemm_hgn_ok(const GemmArgs& a, int cfg) {
   if (cfg < kNumCfgs || cfg >= kNumCfgs + kNumHalo) return false;
   const CfgInfo& c = kHaloCfgs[cfg - kNumCfgs];
   const HaloGn& g = a.hgn;
-  if (!c.hkern_gn || !halo_ok(a, c) || a.accurate || a.ups != 0) return false;
+  if (!c.hkern_gn || !halo_ok(a, c) || a.accurate || a.ups != 0 || c.NT + 64 * c.nw > 1024) return false;
   const int Cin = a.C0 + a.C1;
   if (!g.x0 || !g.gamma || !g.beta || !g.rec0 || g.C0 <= 0 || g.C0 % 64 != 0 || g.C1 % 64 != 0 || g.C0 + g.C1 != Cin || (g.C1 > 0 && (!g.x1 || !g.rec1))) return false;
   if (Cin > 2560 || Cin % 32 != 0 || g.atom <= 0 || (Cin / 32) % g.atom != 0 || g.C0 % g.atom != 0) return false;
   if (g.T0 <= 0 || (g.P0 != 1 && g.P0 != 2) || (g.C1 > 0 && (g.T1 <= 0 || (g.P1 != 1 && g.P1 != 2)))) return false;
-  return halo_lds_bytes(a, c, true, nullptr) <= 160 * 1024;
+  return sdmi_gemm_hgn_depth(a, cfg) >= 2;
+}
+
+// request-ahead distance of the raw pieces: the deepest of 4 .. 1 intervals whose staging slots still fit the LDS (0: none does).
+// Below 2 the pieces arrive too late (measured: one interval costs the conv more than the GroupNorm launch it saves).
+int sdmi_gemm_hgn_depth(const GemmArgs& a, int cfg) {
+  if (cfg < kNumCfgs || cfg >= kNumCfgs + kNumHalo) return 0;
+  static const int max_depth = getenv("SDMI_HALO_GN_DEPTH") ? atoi(getenv("SDMI_HALO_GN_DEPTH")) : 4;
+  GemmArgs t = a;
+  for (int d = max_depth < 4 ? max_depth : 4; d >= 1; --d) {
+    t.hgn.depth = d;
+    if (halo_lds_bytes(t, kHaloCfgs[cfg - kNumCfgs], true, nullptr) <= 160 * 1024) return d;
+  }
+  return 0;
 }
 
 bool sdmi_gemm_acc_ok(int cfg) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].kern_acc != nullptr; }
@@ -1975,15 +2096,20 @@ int sdmi_launch_gemm(const GemmArgs& a, int cfg, hipStream_t st, int* ksplit_out
   if (halo) {
     int halo_bytes = 0;
     const bool gn = a.hgn.x0 != nullptr;
-    if (gn) SDMI_REQUIRE(sdmi_gemm_hgn_ok(a, cfg), "gemm: halo config %s cannot apply GroupNorm to its A operand for this conv", c.name);
-    const int lds = halo_lds_bytes(a, c, gn, &halo_bytes);
+    if (gn) {
+      SDMI_REQUIRE(sdmi_gemm_hgn_ok(a, cfg), "gemm: halo config %s cannot apply GroupNorm to its A operand for this conv", c.name);
+      p.hgn.depth = sdmi_gemm_hgn_depth(a, cfg);
+    }
+    const int lds = halo_lds_bytes(p, c, gn, &halo_bytes);
     SDMI_REQUIRE(lds <= 160 * 1024, "gemm: halo config %s needs %d B of LDS", c.name, lds);
     if (gn) {
-      if (!g_attr_done_hgn[dev][cfg - kNumCfgs]) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)c.hkern_gn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr_done_hgn[dev][cfg - kNumCfgs] = true;
+      const int f32 = a.hgn.in_f32 ? 1 : 0;
+      void (*kern)(GemmArgs, int) = f32 ? c.hkern_gn : c.hkern_gn16;
+      if (!g_attr_done_hgn[dev][cfg - kNumCfgs][f32]) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_done_hgn[dev][cfg - kNumCfgs][f32] = true;
       }
-      hipLaunchKernelGGL(c.hkern_gn, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);
+      hipLaunchKernelGGL(kern, dim3(tiles * p.ksplit), dim3(c.NT + 64 * c.nw), lds, st, p, halo_bytes);      // + the normaliser waves
     } else {
       if (set_attr((const void*)c.hkern, 160 * 1024) != SDMI_OK) return SDMI_EHIP;
       hipLaunchKernelGGL(c.hkern, dim3(tiles * p.ksplit), dim3(c.NT), lds, st, p, halo_bytes);

@@ -628,6 +628,13 @@ int sdmi_op_gemm(const sdmi_gemm_desc* d, void* stream) {
   a.gna_T = d->gna_t; a.gna_parts = d->gna_parts; a.gna_atom = d->gna_atom; a.gna_rows = d->gna_rows;
   a.ksplit = d->ksplit < 1 ? 1 : d->ksplit;
   a.a0f = d->a0f; a.a1f = d->a1f; a.x0f = d->x0f; a.x1f = d->x1f; a.accurate = d->accurate;
+  if (d->hgn_x0) {
+    HaloGn& g = a.hgn;
+    g.x0 = d->hgn_x0; g.x1 = d->hgn_x1; g.in_f32 = d->hgn_in_f32; g.C0 = d->hgn_c0; g.C1 = d->hgn_c1;
+    g.gamma = d->hgn_gamma; g.beta = d->hgn_beta; g.eps = d->hgn_eps; g.silu = d->hgn_silu;
+    g.rec0 = d->hgn_rec0; g.rec1 = d->hgn_rec1; g.T0 = d->hgn_t0; g.T1 = d->hgn_t1; g.P0 = d->hgn_p0; g.P1 = d->hgn_p1; g.atom = d->hgn_atom;
+    if (!a.a0) a.a0 = (const f16*)d->hgn_x0;                 // (the launcher's null check; never read)
+  }
   if (a.accurate) a.a0 = a.a0 ? a.a0 : (const f16*)d->a0f;          // (the launcher's null check; never read)
   int cfg = d->cfg;
   if (a.accurate && cfg < 0) {
@@ -707,7 +714,8 @@ int sdmi_op_b2b(const sdmi_b2b_desc* d, int iters, float* us_per_iter, void* str
   if (d->gacc) {
     SDMI_REQUIRE(d->gacc_atom >= 4 && 320 % d->gacc_atom == 0 && d->gacc_rows_img > 0, "op_b2b: bad statistics arguments");
     a.gacc.rec = d->gacc; a.gacc.atom = d->gacc_atom; a.gacc.natoms = 320 / d->gacc_atom; a.gacc.rows_img = d->gacc_rows_img; a.gacc.mod = d->M;
-    a.gacc.T = d->gacc_rows_img / 32; a.gacc.parts = 1;          // one record row per 32-row tile
+    const int bm = d->bm ? d->bm : sdmi_b2b_tile_rows(a);
+    a.gacc.T = d->gacc_rows_img / bm; a.gacc.parts = 1;          // one record row per tile of bm rows
   }
   hipStream_t st = (hipStream_t)stream;
   if (!us_per_iter) {

@@ -49,7 +49,7 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
           out_f32=False, cfg=-1, ksplit=1, out_t=None, nt0=0, S=0, ldt=0, want16=False, x0=None, x1=None,
           rowstat=None, ln_stat=None, ln_g=None, ln_c=0, ln_eps=1e-5, out_t_perm=0, act=0, sm_valid=0, img_rows=0,
           w_img_stride=0, vec_img_stride=0, ldw=0, n_out=None, phase2=0, ln_ksteps=0, ln_out=None, gstat_rows_img=0, gstat_atom=10, ln_guard=None,
-          ln_guard_sigma=8.0, gna=None, accurate=False, a0f=None, a1f=None, x0f=None, x1f=None):
+          ln_guard_sigma=8.0, gna=None, accurate=False, a0f=None, a1f=None, x0f=None, x1f=None, hgn=None):
     """a0/a1: NHWC fp16 (B,Hs,Ws,C).  Returns out [M][N'] (N' = nt0 if out_t given).
     gstat_rows_img > 0: the launch also leaves the GroupNorm statistics of its output (sdmi_gemm_desc::gacc); they are returned
     in LAST_STAT = (records [images][T][atoms][parts][2] fp32, T, parts).  ValueError if the config cannot take them."""
@@ -94,6 +94,17 @@ def igemm(a0, w_packed, *, B, Hs, Ws, Ho, Wo, ks=1, stride=1, ups=0, a1=None, bi
         rec, gamma, beta, eps, rows = gna
         d.gna_rec, d.gna_gamma, d.gna_beta, d.gna_eps = rec.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps
         d.gna_t, d.gna_parts, d.gna_atom, d.gna_rows = rec.shape[1], rec.shape[3], c0 // rec.shape[2], rows
+    if hgn is not None:        # GroupNorm(+SiLU) inside the halo conv: dict(x0, x1, gamma, beta, eps, silu, rec0, rec1) -- a0 only gives the shape
+        x0r, x1r = hgn["x0"], hgn.get("x1")
+        d.hgn_x0 = x0r.data_ptr(); d.hgn_x1 = 0 if x1r is None else x1r.data_ptr()
+        d.hgn_in_f32 = int(x0r.dtype == torch.float32)
+        d.hgn_c0, d.hgn_c1 = x0r.shape[-1], 0 if x1r is None else x1r.shape[-1]
+        d.hgn_gamma, d.hgn_beta, d.hgn_eps, d.hgn_silu = hgn["gamma"].data_ptr(), hgn["beta"].data_ptr(), hgn["eps"], int(hgn["silu"])
+        r0, r1 = hgn["rec0"], hgn.get("rec1")          # records [images][T][atoms][parts][2] fp32
+        d.hgn_rec0, d.hgn_t0, d.hgn_p0 = r0.data_ptr(), r0.shape[1], r0.shape[3]
+        d.hgn_atom = d.hgn_c0 // r0.shape[2]
+        if r1 is not None:
+            d.hgn_rec1, d.hgn_t1, d.hgn_p1 = r1.data_ptr(), r1.shape[1], r1.shape[3]
     if accurate:               # the wide-operand kernels: fp32 copies of every A source (a0 / a1 / x0 / x1 only give the shapes)
         d.accurate = 1
         d.a0f = a0f.data_ptr(); d.a1f = 0 if a1f is None else a1f.data_ptr()

@@ -812,6 +812,41 @@ def test_gemm_epilogue_groupnorm_statistics(B, P, Nn, K, ksplit, out_f32):
     assert tried >= (1 if ksplit > 1 else 8), tried
 
 
+@pytest.mark.parametrize("B,Hh,Cin,Co,out_f32", [(2, 16, 128, 320, True), (2, 16, 64, 160, False), (1, 32, 64, 640, True)])
+def test_conv_160_wide_tile_statistics(B, Hh, Cin, Co, out_f32):
+    """The 160-wide conv tiles (N = 320 / 640 / 1280 divide by 160; the plans of the batched multi-prompt mode) leave the GroupNorm
+    statistics of their output too (csrc/gemm.hip store_tile GACC160): column sums taken from the tile the epilogue rewrote, whole
+    10-channel atoms per tile.  Records against the moments of exactly the stored values; two launches give the same bits."""
+    lib = N_.load()
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    g = torch.Generator().manual_seed(B * 100 + Co)
+    x = torch.randn((B, Hh, Hh, Cin), generator=g).half()
+    w = (torch.randn((Co, Cin, 3, 3), generator=g) / math.sqrt(9 * Cin)).half().float()
+    bias = torch.randn((Co,), generator=g) * 2
+    wp = G.pack_conv(w.to(DEV))
+    P = Hh * Hh
+    ran = 0
+    for cfg in [i for i, nm in enumerate(names) if "x160" in nm]:
+        kw = dict(B=B, Hs=Hh, Ws=Hh, Ho=Hh, Wo=Hh, ks=3, bias=bias.to(DEV), out_f32=out_f32, cfg=cfg, gstat_rows_img=P)
+        try:
+            out = G.igemm(x.to(DEV), wp, **kw)
+        except ValueError as exc:
+            assert "not applicable" in str(exc) or "cannot" in str(exc) or "LDS" in str(exc), exc
+            continue
+        ran += 1
+        rec, T, parts = G.LAST_STAT
+        assert parts == 2 and not torch.isnan(rec).any(), f"{names[cfg]}: record slots never written"
+        s1, s2 = G.stat_moments(rec)
+        r1, r2 = _atom_moments(out.cpu().double().view(B * P, Co), B)
+        e1 = ((s1 - r1).abs() / (r1.abs() + P * 1.0)).max().item()
+        e2 = ((s2 - r2).abs() / r2).max().item()
+        assert e1 < 2e-6 and e2 < 2e-6, f"{names[cfg]}: sum err {e1}, sumsq err {e2}"
+        assert bool((rec[..., 1, :] == 0).all())                  # whole atoms per tile: the second part stays zero
+        out2 = G.igemm(x.to(DEV), wp, **kw)
+        assert torch.equal(out, out2) and torch.equal(rec, G.LAST_STAT[0])
+    assert ran >= 2, ran
+
+
 def test_statistics_follow_the_effective_split_k():
     """A split-K request the launcher clamps away (K = 64 is ONE K-step: ksplit 2 runs as 1) must not leave the one-pass
     epilogue writing parts = 2 records into a table laid out for the combine's parts = 1 (past its end from the second image on):
@@ -881,6 +916,86 @@ def test_groupnorm_from_producer_statistics(C0, C1, P, in_f32, silu, offset):
     assert d2 < 4e-3, f"differs from the statistics-launch path by {d2}"
 
 
+def _records_of(x_nhwc, atom, T, parts, gen):
+    """statistics records of a tensor as a producer would have left them (common.h GnRec: [image][T][atoms][parts][2] fp32): the
+    moments of each 10-channel atom over T row blocks; with parts = 2 every record is split arbitrarily between its two parts"""
+    B, Hh, Ww, Cc = x_nhwc.shape
+    P = Hh * Ww
+    xa = x_nhwc.double().reshape(B, T, P // T, Cc // atom, atom)
+    s1, s2 = xa.sum(dim=(2, 4)), (xa * xa).sum(dim=(2, 4))                   # [B][T][atoms]
+    rec = torch.zeros((B, T, Cc // atom, parts, 2), dtype=torch.float32)
+    if parts == 1:
+        rec[..., 0, 0], rec[..., 0, 1] = s1.float(), s2.float()
+    else:
+        f = torch.rand(s1.shape, generator=gen).double()
+        rec[..., 0, 0], rec[..., 0, 1] = (s1 * f).float(), (s2 * f).float()
+        rec[..., 1, 0], rec[..., 1, 1] = (s1 * (1 - f)).float(), (s2 * (1 - f)).float()
+    return rec
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=32, W=32, C0=320, C1=0, Co=320, f32=True, silu=1, offset=0.0, T=8, parts=2, atom=10),       # a 32x32 ResBlock conv
+    dict(B=2, H=32, W=32, C0=128, C1=128, Co=128, f32=True, silu=1, offset=0.0, T=4, parts=1, atom=4),      # concat of two sources
+    dict(B=1, H=64, W=64, C0=128, C1=0, Co=128, f32=False, silu=1, offset=0.0, T=32, parts=2, atom=4),      # fp16 source (conv_merged's input), W = 64
+    dict(B=2, H=16, W=16, C0=640, C1=640, Co=160, f32=True, silu=0, offset=0.0, T=1, parts=1, atom=10),     # 16x16, 1280 channels, 160-wide tile, no SiLU
+    dict(B=2, H=32, W=32, C0=320, C1=0, Co=64, f32=True, silu=1, offset=30.0, T=8, parts=1, atom=10),       # |mean| = 30 sigma
+    dict(B=2, H=32, W=32, C0=320, C1=0, Co=64, f32=True, silu=1, offset=-100.0, T=8, parts=1, atom=10),     # |mean| = 100 sigma
+])
+def test_conv_with_groupnorm_inside(case):
+    """GroupNorm -> SiLU -> conv3x3 as ONE launch (include/sdmi.h sdmi_gemm_desc::hgn_*, csrc/gemm.hip conv3_halo_kernel<.., GN>;
+    sd/diffusion.py:173-179,199-205): the halo conv's producer waves normalise the raw tensor(s) from their producers' statistics
+    records.  Against (1) the fp64 GroupNorm(+SiLU) rounded to fp16 -- what the normalising launch writes -- through an fp64 conv,
+    and (2) the library's own two-launch path (sdmi_op_groupnorm_acc + the same conv config).  Rows whose mean is 30 / 100 sigma
+    from zero included (the offsets of test_groupnorm_large_mean): the raw tensor is read in fp32, so a large mean costs what it
+    costs the separate kernel.  Every halo config built with the variant, one-pass and split-K."""
+    c = case
+    g = torch.Generator().manual_seed(c["C0"] + c["Co"] + int(abs(c["offset"])))
+    mk = lambda ch: torch.randn((c["B"], c["H"], c["W"], ch), generator=g) * (1 + 0.5 * torch.rand((ch,), generator=g)) + c["offset"] + 0.3 * torch.randn((ch,), generator=g)
+    x0, x1 = mk(c["C0"]), (mk(c["C1"]) if c["C1"] else None)
+    if not c["f32"]:
+        x0 = x0.half().float()
+        x1 = None if x1 is None else x1.half().float()
+    cin = c["C0"] + c["C1"]
+    gamma = 1 + 0.2 * torch.randn((cin,), generator=g)
+    beta = 0.2 * torch.randn((cin,), generator=g)
+    w = (torch.randn((c["Co"], cin, 3, 3), generator=g) / math.sqrt(9 * cin)).half().float()
+    xin = x0 if x1 is None else torch.cat([x0, x1], -1)
+    yn = F.group_norm(xin.double().permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-5)
+    yn = (F.silu(yn) if c["silu"] else yn).permute(0, 2, 3, 1)
+    ref = _conv_ref_f64(yn.half().float(), w, 1, 0)                       # the conv's operand is the fp16-rounded normalised tensor
+    wp = G.pack_conv(w.to(DEV))
+    dt = torch.float32 if c["f32"] else torch.float16
+    x0d, x1d = x0.to(DEV, dt), (None if x1 is None else x1.to(DEV, dt))
+    rec0 = _records_of(x0, c["atom"], c["T"], c["parts"], g).to(DEV)
+    rec1 = None if x1 is None else _records_of(x1, c["atom"], max(1, c["T"] // 2), 1, g).to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    # the two-launch path: the normalising kernel from the same records, then the plain conv
+    st = lambda r: None if r is None else (r, r.shape[1], r.shape[3])
+    t0 = G.groupnorm_acc(x0d, x1d, st(rec0), st(rec1), gd, bd, 1e-5, c["silu"], atom=c["atom"])
+    shape = torch.empty((c["B"], c["H"], c["W"], cin), dtype=torch.float16, device=DEV)        # a0 of the fused launch: shape only
+    lib = N_.load()
+    names = [lib.sdmi_gemm_config_name(i).decode() for i in range(lib.sdmi_gemm_num_configs())]
+    ran = 0
+    sc = ref.abs().mean().item()
+    for cfg in [i for i, nm in enumerate(names) if nm[0] == "h"]:
+        for ksplit in (1, 2, 3):
+            kw = dict(B=c["B"], Hs=c["H"], Ws=c["W"], Ho=c["H"], Wo=c["W"], ks=3, out_f32=True, cfg=cfg, ksplit=ksplit)
+            try:
+                out = G.igemm(shape, wp, hgn=dict(x0=x0d, x1=x1d, gamma=gd, beta=bd, eps=1e-5, silu=c["silu"], rec0=rec0, rec1=rec1), **kw)
+            except ValueError as exc:
+                assert "cannot apply GroupNorm" in str(exc) or "not applicable" in str(exc) or "LDS" in str(exc), exc
+                continue
+            two = G.igemm(t0.view(c["B"], c["H"], c["W"], cin), wp, **kw)
+            ran += 1
+            err = (out.cpu().double().view(ref.shape) - ref).abs().max().item()
+            d2 = (out - two).abs().max().item()
+            G.log_metric(test="conv_gn_inside", case=str(c), cfg=names[cfg], ksplit=ksplit, max_abs_err=err, vs_two_launches=d2, out_scale=sc)
+            tol = 3e-3 if abs(c["offset"]) <= 30 else 8e-3
+            assert err < tol, f"{c} {names[cfg]} split {ksplit}: max abs err {err} (outputs ~{sc:.2f})"
+            assert d2 < tol, f"{c} {names[cfg]} split {ksplit}: differs from GroupNorm launch + conv by {d2}"
+    assert ran >= 2, f"no halo config ran the variant ({ran})"
+
+
 @pytest.mark.parametrize("C,P,offset,parts", [(640, 1024, 0.0, 2), (1280, 256, 0.0, 1), (640, 1024, 10.0, 2), (1280, 64, 30.0, 1), (320, 4096, -30.0, 2)])
 def test_gemm_groupnorm_on_a_fragments(C, P, offset, parts):
     """GroupNorm (no SiLU, eps 1e-6) -> 1x1 conv (the attention block's groupnorm -> conv_input, sd/diffusion.py:294-298) as ONE
@@ -926,8 +1041,8 @@ def test_gemm_groupnorm_on_a_fragments(C, P, offset, parts):
     assert ran >= 3, "no config ran the variant"
 
 
-@pytest.mark.parametrize("offset", [2.0, 30.0, -100.0])
-def test_back_to_back_gemm_groupnorm_statistics(offset):
+@pytest.mark.parametrize("offset,bm", [(2.0, 32), (30.0, 32), (-100.0, 32), (2.0, 64), (30.0, 64)])
+def test_back_to_back_gemm_groupnorm_statistics(offset, bm):
     """the feed-forward form of csrc/b2b.hip (the attention block's output at 64x64) leaves the statistics of its output: the
     moments of WHAT THE GROUPNORM WILL READ -- the fp32 stream when there is one (as store_tile, splitk_finalize and the stem take
     them), also where the group's mean is 30 / 100 sigma away from zero and the fp16 shadow is 2^-11 |mean| off"""
@@ -952,14 +1067,14 @@ def test_back_to_back_gemm_groupnorm_statistics(offset):
     for with_acc in (False, True):
         out = torch.full((M, Cc), float("nan"), device=DEV)
         out16 = torch.full((M, Cc), float("nan"), dtype=torch.float16, device=DEV)
-        rec = torch.full((B, P // 32, Cc // 10, 1, 2), float("nan"), device=DEV)
+        rec = torch.full((B, P // bm, Cc // 10, 1, 2), float("nan"), device=DEV)       # one record row per bm-row tile (the 64-row form too: round 5)
         d = N_.B2bDesc()
         d.a1, d.lda1, d.w1, d.b1 = a1d.data_ptr(), Cc, w1d.data_ptr(), b1d.data_ptr()
         d.r1, d.r1_f32 = r1d.data_ptr(), 1
         d.w2, d.K2, d.h2, d.partial, d.cscale = wf.data_ptr(), 640, hf.data_ptr(), 1, 0.0
         d.r2, d.r2_f32 = r2d.data_ptr(), 1
         d.out, d.out_f32, d.out16 = out.data_ptr(), 1, out16.data_ptr()
-        d.M, d.eps, d.bm = M, 1e-5, 32
+        d.M, d.eps, d.bm = M, 1e-5, bm
         if with_acc:
             d.gacc, d.gacc_atom, d.gacc_rows_img = rec.data_ptr(), 10, P
         N_.check(N_.load().sdmi_op_b2b(C.byref(d), 1, None, N_.cur_stream()), "b2b")
