@@ -919,7 +919,9 @@ struct Engine {
   // intermediate are gone; the conv's producer waves normalise the pieces of the halo image they stage anyway.
   // `a` describes the conv on the MATERIALISED normalised tensor (C0 = all channels, C1 = 0: that is also its plan key); on
   // success a.hgn is filled and the caller must not launch the GroupNorm.  SDMI_HALO_GN=0: never.
-  static bool halo_gn_on() { static const bool on = !(getenv("SDMI_HALO_GN") && atoi(getenv("SDMI_HALO_GN")) == 0); return on; }
+  // opt-in (SDMI_HALO_GN=1): measured 0.7 - 1.5 % SLOWER per step than the separate GroupNorm launch (DESIGN.md section 8.2:
+  // each of the N / BN column tiles re-normalises the same input and SiLU's two transcendentals are quarter rate)
+  static bool halo_gn_on() { static const bool on = getenv("SDMI_HALO_GN") && atoi(getenv("SDMI_HALO_GN")) != 0; return on; }
   bool try_halo_gn(GemmArgs& a, const Act& x, const Act* x1, const NormW& w, float eps, int silu) {
     if (!halo_gn_on() || accurate || pend) return false;
     if (!x.gok || !x.grec || (x1 && (!x1->gok || !x1->grec))) return false;
