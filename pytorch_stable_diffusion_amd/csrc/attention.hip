@@ -29,6 +29,16 @@
 #define SDMI_ATTN_ABLATE 0
 #endif
 
+#ifdef SDMI_ATTN_PROBE
+// diagnostic build (tools/build_variant.sh probe attention -DSDMI_ATTN_PROBE): shader-clock cycles every wave of the first 512 workgroups
+// spends in the parts of its tile loop, summed over the tiles: {stage issue, tile body, -, DMA wait, barrier, tiles, whole life, life in 100 MHz ticks}
+__device__ unsigned long long g_attn_clk[4096][8];   // [6], [7]: shader clocks and 100 MHz ticks of the wave's whole life
+extern "C" int sdmi_dbg_read_attn(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_clk), (size_t)n * 64) == hipSuccess ? 0 : -5;
+}
+#define ATTN_T() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -70,6 +80,64 @@ __device__ __forceinline__ void wait_vm_upto(int n) {
 #undef SDMI_VM_CASE
 }
 
+// The end of every form: (SPLIT) the wave pair's two key halves meet through LDS, then O / l is written (fp16, and fp32 for the
+// accurate mode).  `smem` is the start of the dynamic LDS: the K/V stages are dead by now and hold the exchange.
+template <int D, bool SPLIT>
+__device__ __forceinline__ void attn_finish(const AttnArgs& p, char* smem, f32x16 (&oacc)[ACfg<D>::DB], float m_run, float l_run,
+                                            int wave, int lane, int hk, int q0, int b, int head) {
+  typedef ACfg<D> C;
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (SPLIT) {
+    // merge the pair's halves: wave hk = 1 hands (m, l, O^T) over through LDS (aliasing the K/V stages: every tile has been
+    // consumed), wave hk = 0 combines: m = max, O = O_a 2^(m_a - m) + O_b 2^(m_b - m) (the row of ones in V^T carries l
+    // along inside O for d = 40 / 80; d = 160 merges l_run explicitly), then normalises and stores as usual.
+    constexpr int NV = C::DB * 16 + 2;
+    __syncthreads();
+    float* mx = (float*)smem + ((size_t)(wave >> 1) * 64 + lane) * NV;
+    if (hk == 1) {
+#pragma unroll
+      for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx[d * 16 + e] = oacc[d][e];
+      mx[C::DB * 16] = m_run;
+      mx[C::DB * 16 + 1] = l_run;
+    }
+    __syncthreads();
+    if (hk == 1) return;
+    const float m_b = mx[C::DB * 16], l_b = mx[C::DB * 16 + 1];
+    const float m = fmaxf(m_run, m_b);
+    const float sa = __builtin_amdgcn_exp2f(m_run - m), sb = __builtin_amdgcn_exp2f(m_b - m);
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] = oacc[d][e] * sa + mx[d * 16 + e] * sb;
+    l_run = l_run * sa + l_b * sb;
+  }
+  // ---- normalise and store: lane = query row, registers = head-dim ----
+  float l_tot;
+  if constexpr (C::LROW) l_tot = __shfl(oacc[D / 32][4 * ((D % 32) / 8)], r);   // accumulator row D (lane r of the low half)
+  else l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qi = q0 + r;
+  if (qi < p.Sq) {
+    f16* op = p.o + ((size_t)b * p.Sq + qi) * p.ldo + head * D;
+#pragma unroll
+    for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * h;
+        if (dd < D) {
+          f16x4 o4;
+          f32x4 of;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { of[e] = oacc[d][4 * g + e] * inv; o4[e] = (f16)of[e]; }
+          *(f16x4*)(op + dd) = o4;
+          if (p.o32) *(f32x4*)(p.o32 + ((size_t)b * p.Sq + qi) * p.ldo + head * D + dd) = of;
+        }
+      }
+  }
+}
+
 // NW = waves per workgroup: 4, or 8 for the key-split form over 128 queries (long sequences: four waves per SIMD at the
 // same K/V bytes staged per query as the unsplit form).
 // NB = depth of the K/V ring in LDS.  2: the tiles of step t+1 are requested when step t starts and waited for (vmcnt(0)) when it
@@ -88,6 +156,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   constexpr int STAGE2 = NSUB * C::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef SDMI_ATTN_PROBE
+  const unsigned long long life_c0 = ATTN_T(), life_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   int qtile, bh;
@@ -338,19 +409,41 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   // Three runs of tiles, each with ONE body in its loop (separate loops keep the accumulators in place: with both
   // bodies in one loop the register allocator copied all of O^T every tile): tile 0, unmasked tiles, masked tail.
   int cur = 0, nxt = NB - 1;
+#ifdef SDMI_ATTN_PROBE
+  unsigned long long pa[6] = {0, 0, 0, 0, 0, 0};
+#endif
   auto step = [&](int t, auto masked_tag, auto first_tag) {
     // the buffer written here was last read in step t-1 (NB = 3: it holds tile t+2, NB = 2: tile t+1); the barrier that ended
     // step t-1 closed that WAR window
+#ifdef SDMI_ATTN_PROBE
+    const unsigned long long c0 = ATTN_T();
+#endif
     if (!(SDMI_ATTN_ABLATE & 8) && t + NB - 1 < ntiles) stage(nxt);
+#ifdef SDMI_ATTN_PROBE
+    const unsigned long long c1 = ATTN_T();
+#endif
     tile_body(masked_tag, first_tag, t, cur);
+#ifdef SDMI_ATTN_PROBE
+    const unsigned long long c2 = ATTN_T();
+    unsigned long long c3 = c2, c4 = c2;
+#endif
     if (!(SDMI_ATTN_ABLATE & 16) && t + 1 < ntiles) {
       // RAW for step t+1: every wave waits for ITS pieces of tile t+1, then the barrier publishes them.  NB = 3: the stage
       // issued in this step (tile t+2) stays in flight -- a plain s_barrier, not __syncthreads(), whose fence would drain it
       if (NB == 3 && t + 2 < ntiles) wait_vm_upto(per_stage);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SDMI_ATTN_PROBE
+      c3 = ATTN_T();
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#ifdef SDMI_ATTN_PROBE
+      c4 = ATTN_T();
+#endif
     }
+#ifdef SDMI_ATTN_PROBE
+    pa[0] += c1 - c0; pa[1] += c2 - c1; pa[3] += c3 - c2; pa[4] += c4 - c3; pa[5] += 1;
+#endif
     cur = cur + 1 == NB ? 0 : cur + 1;
     nxt = nxt + 1 == NB ? 0 : nxt + 1;
   };
@@ -359,56 +452,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
   int t = 1;
   for (; t < nfull; ++t) step(t, std::false_type{}, std::false_type{});
   for (; t < ntiles; ++t) step(t, std::true_type{}, std::false_type{});
+#ifdef SDMI_ATTN_PROBE
+  if (lane == 0 && blockIdx.x < 512 && NW == 8) {
+    unsigned long long* o = g_attn_clk[blockIdx.x * 8 + wave];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = pa[i];
+  }
+#endif
 
-  if constexpr (SPLIT) {
-    // merge the pair's halves: wave hk = 1 hands (m, l, O^T) over through LDS (aliasing the K/V stages: every tile has been
-    // consumed), wave hk = 0 combines: m = max, O = O_a 2^(m_a - m) + O_b 2^(m_b - m) (the row of ones in V^T carries l
-    // along inside O for d = 40 / 80; d = 160 merges l_run explicitly), then normalises and stores as usual.
-    constexpr int NV = C::DB * 16 + 2;
-    __syncthreads();
-    float* mx = (float*)smem + ((size_t)(wave >> 1) * 64 + lane) * NV;
-    if (hk == 1) {
-#pragma unroll
-      for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx[d * 16 + e] = oacc[d][e];
-      mx[C::DB * 16] = m_run;
-      mx[C::DB * 16 + 1] = l_run;
-    }
-    __syncthreads();
-    if (hk == 1) return;
-    const float m_b = mx[C::DB * 16], l_b = mx[C::DB * 16 + 1];
-    const float m = fmaxf(m_run, m_b);
-    const float sa = __builtin_amdgcn_exp2f(m_run - m), sb = __builtin_amdgcn_exp2f(m_b - m);
-#pragma unroll
-    for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[d][e] = oacc[d][e] * sa + mx[d * 16 + e] * sb;
-    l_run = l_run * sa + l_b * sb;
-  }
-  // ---- normalise and store: lane = query row, registers = head-dim ----
-  float l_tot;
-  if constexpr (C::LROW) l_tot = __shfl(oacc[D / 32][4 * ((D % 32) / 8)], r);   // accumulator row D (lane r of the low half)
-  else l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  const int qi = q0 + r;
-  if (qi < p.Sq) {
-    f16* op = p.o + ((size_t)b * p.Sq + qi) * p.ldo + head * D;
-#pragma unroll
-    for (int d = 0; d < C::DB; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dd = d * 32 + 8 * g + 4 * h;
-        if (dd < D) {
-          f16x4 o4;
-          f32x4 of;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { of[e] = oacc[d][4 * g + e] * inv; o4[e] = (f16)of[e]; }
-          *(f16x4*)(op + dd) = o4;
-          if (p.o32) *(f32x4*)(p.o32 + ((size_t)b * p.Sq + qi) * p.ldo + head * D + dd) = of;
-        }
-      }
-  }
+#ifdef SDMI_ATTN_PROBE
+  if (lane == 0 && blockIdx.x < 512 && NW == 8) { g_attn_clk[blockIdx.x * 8 + wave][6] = ATTN_T() - life_c0; g_attn_clk[blockIdx.x * 8 + wave][7] = __builtin_amdgcn_s_memrealtime() - life_r0; }
+#endif
+  attn_finish<D, SPLIT>(p, smem, oacc, m_run, l_run, wave, lane, hk, q0, b, head);
 }
 
 template <int D>
