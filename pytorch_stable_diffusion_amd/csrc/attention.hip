@@ -149,6 +149,7 @@ __device__ __forceinline__ void attn_finish(const AttnArgs& p, char* smem, f32x1
 // With two heads per XCD their K/V (1.3 MB) stay in that XCD's L2.  Speed only: any placement gives the same result.
 template <int D, bool SPLIT, int NW = 4, int NB = 2>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs p) {
+  sdmi_kernarg_warm<sizeof(AttnArgs) + 16>();     // + the hidden grid size (gridDim.x)
   typedef ACfg<D> C;
   static_assert(NW == 4 || (SPLIT && NW == 8), "8-wave workgroups only in the key-split form");
   static_assert(NB == 2 || NB == 3, "ring depth");
