@@ -249,6 +249,24 @@ def test_attention_blocks_with_separate_layernorm_kernel():
     assert "passed" in r.stdout
 
 
+def test_resblocks_with_groupnorm_inside_the_conv(tmp_path):
+    """SDMI_HALO_GN=1 (opt-in): GroupNorm + SiLU of the ResBlocks applied inside the halo 3x3 conv (gemm.hip conv3_halo_kernel<.., GN>,
+    sd/diffusion.py:173-179,199-205) -- the ResBlock goldens and the 64x64 full-UNet golden at the same bounds, and the launch log of
+    the child must show fused launches ("+gn").  The knob is read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+    log = tmp_path / "launch.log"
+    env = dict(os.environ, SDMI_HALO_GN="1", SDMI_LAUNCH_LOG=str(log))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_unet.py", "-k",
+                        "(test_block_vs_golden and res_) or (test_full_unet_vs_golden and 64-980)"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
+    assert "+gn" in log.read_text(), "no conv of the last forward ran with the GroupNorm inside"
+
+
 def test_no_tune_flag_parity():
     """SDMI_FLAG_NO_TUNE: heuristic tile choice (gemm.hip pick_cfg), no timing runs -- same parity as the tuned plans."""
     from pytorch_stable_diffusion_amd import _native as N
