@@ -84,11 +84,20 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
 // registers per lane -- two workgroups per CU, two rounds of workgroups on the 64x64 maps; this one stays under 128 at 16
 // statistics loads in flight per thread.
 constexpr int GNA_NT = 512, GNA_IT = 2, GNA_SH = GNA_NT / 32;      // threads, items per thread, shares per group
+constexpr int GNA_MAXC = 2560, GNA_NCH = GNA_MAXC / GNA_NT;        // channels (launcher: C / 8 <= 320); table channels per thread
 __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_per_block) {
   sdmi_kernarg_warm<sizeof(GnArgs) + 4>();     // one miss latency for the argument block instead of one per line the compiler reaches for (common.h)
   __shared__ double s_red[GNA_SH][32][2];
   __shared__ float s_mean[32], s_rstd[32];
+  // per-channel {mean of the group, rstd * gamma, beta}: built once per workgroup behind the statistics and read as 16-byte
+  // vectors in phase B (round 5).  Before, every thread fetched its items' gamma / beta itself -- 64 bytes per item through the
+  // CU's one texture path beside the 32 bytes of the item, and 32 registers held across the statistics -- and looked the group
+  // of every element up in s_mean / s_rstd with scalar LDS reads.  Same arithmetic per element: (x - mean) * (rstd gamma) + beta.
+  extern __shared__ __attribute__((aligned(16))) float gna_tab[];      // 3 C floats (launcher)
   const int C = p.C0 + p.C1, C8 = C / 8, cpg = C / 32;
+  float* const t_mean = gna_tab;
+  float* const t_a = gna_tab + C;
+  float* const t_b = gna_tab + 2 * C;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
@@ -97,7 +106,6 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
   const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 2 per thread
   constexpr int IT = GNA_IT;
   float v[IT][8];
-  f32x4 ga_[IT], gb_[IT], ba_[IT], bb_[IT];
   int px_[IT], c_[IT];
   bool ok[IT];
   const int q_first = tid / C8, r_first = tid - q_first * C8;     // item = tid + NT k -> (pixel, chunk) incrementally
@@ -116,10 +124,15 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     const int cs = second ? p.C1 : p.C0;
     const int cc = second ? c_[k] - p.C0 : c_[k];
     if (ok[k]) load8(base, p.in_f32, ((size_t)n * p.P + px_[k]) * cs + cc, v[k]);
-    // the layer's gamma / beta come from HBM (every weight is read once per step): requested here, with the activations,
-    // instead of behind the statistics (one more exposed memory latency per launch)
-    ga_[k] = *(const f32x4*)(p.gamma + c_[k]); gb_[k] = *(const f32x4*)(p.gamma + c_[k] + 4);
-    ba_[k] = *(const f32x4*)(p.beta + c_[k]); bb_[k] = *(const f32x4*)(p.beta + c_[k] + 4);
+  }
+  // the layer's gamma / beta come from HBM (every weight is read once per step): requested here, with the activations, instead of
+  // behind the statistics (one more exposed memory latency per launch) -- one channel per thread and round, for the table
+  float gm[GNA_NCH], bt[GNA_NCH];
+#pragma unroll
+  for (int k = 0; k < GNA_NCH; ++k) {
+    const int c = tid + k * GNA_NT;
+    gm[k] = c < C ? p.gamma[c] : 0.f;
+    bt[k] = c < C ? p.beta[c] : 0.f;
   }
   const int g = tid & 31, sl = tid >> 5;
   if (p.acc0 != nullptr) {
@@ -192,24 +205,33 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     s_rstd[tid] = rsqrtf((float)var + p.eps);
   }
   __syncthreads();
+  {
+    const unsigned magic = ((1u << 20) + cpg - 1) / cpg;      // c / cpg == (c * magic) >> 20 for c < 2560, cpg <= 80
+#pragma unroll
+    for (int k = 0; k < GNA_NCH; ++k) {
+      const int c = tid + k * GNA_NT;
+      if (c < C) {
+        const int gg = (int)(((unsigned)c * magic) >> 20);
+        t_mean[c] = s_mean[gg];
+        t_a[c] = s_rstd[gg] * gm[k];
+        t_b[c] = bt[k];
+      }
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < IT; ++k) {               // phase B: normalise (+SiLU), convert, store
     if (!ok[k]) continue;
     const int c = c_[k];
-    const f32x4 ga = ga_[k], gb = gb_[k], ba = ba_[k], bb = bb_[k];
+    const f32x4 m0 = *(const f32x4*)(t_mean + c), m1 = *(const f32x4*)(t_mean + c + 4);
+    const f32x4 a0 = *(const f32x4*)(t_a + c), a1 = *(const f32x4*)(t_a + c + 4);
+    const f32x4 b0 = *(const f32x4*)(t_b + c), b1 = *(const f32x4*)(t_b + c + 4);
     f16x8 o;
     float yf[8];
-    const int g0 = c / cpg;                      // one division per item; cpg >= 4, so c+e is at most 2 groups further
-    const int r0 = c - g0 * cpg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int gg = g0, rr2 = r0 + e;
-      if (rr2 >= cpg) { rr2 -= cpg; ++gg; }
-      if (rr2 >= cpg) { rr2 -= cpg; ++gg; }
-      if (rr2 >= cpg) ++gg;
-      const float gam = e < 4 ? ga[e] : gb[e - 4];
-      const float bet = e < 4 ? ba[e] : bb[e - 4];
-      float y = (v[k][e] - s_mean[gg]) * s_rstd[gg] * gam + bet;
+      const float mu = e < 4 ? m0[e] : m1[e - 4], aa = e < 4 ? a0[e] : a1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
+      float y = (v[k][e] - mu) * aa + bb;
       if (p.silu) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));     // v_rcp_f32 (1 ulp), not the ~10-instruction IEEE division
       o[e] = (f16)y;
       yf[e] = y;
@@ -448,6 +470,17 @@ int sdmi_gn_launches(const GnArgs& a) {
   const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
   return (cpg % 4 == 0 && cpg <= 128 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
 }
+// diagnostic knob (A/B only): extra dynamic LDS per gn_apply workgroup caps the workgroups per CU
+static int gna_lds_pad() {
+  static const int pad = getenv("SDMI_GNA_LDS_PAD") ? atoi(getenv("SDMI_GNA_LDS_PAD")) : 0;
+  static bool attr = false;
+  if (pad > 0 && !attr) {
+    if (hipFuncSetAttribute((const void*)gn_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) fprintf(stderr, "gn_apply: LDS attribute refused\n");
+    attr = true;
+  }
+  return pad;
+}
+
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   const int C = a.C0 + a.C1;
   SDMI_REQUIRE(C % 32 == 0 && C % 8 == 0 && a.C0 % 8 == 0, "groupnorm: C=%d (C0=%d) must be multiples of 32/8", C, a.C0);
@@ -464,7 +497,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
     const int C8a = C / 8;
     int ppb = (256 * 4) / C8a;
     if (ppb < 1) ppb = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(GNA_NT), 0, st, a, ppb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(GNA_NT), 3 * C * sizeof(float) + gna_lds_pad(), st, a, ppb);
     SDMI_CHECK_HIP(hipGetLastError());
     return SDMI_OK;
   }
@@ -493,7 +526,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   int ppb = (256 * 4) / C8;
   if (ppb < 1) ppb = 1;
   const int nblk = (a.P + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(GNA_NT), 0, st, a, ppb);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(GNA_NT), 3 * C * sizeof(float) + gna_lds_pad(), st, a, ppb);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
