@@ -9,6 +9,18 @@
 // in registers, fp16 out.  Statistics are fp32; biased variance like torch.
 #include "common.h"
 
+#ifdef SDMI_GNA_PROBE
+// diagnostic build (tools/build_variant.sh probe norm -DSDMI_GNA_PROBE): shader-clock stamps of thread 0 of the first 2048 workgroups of
+// gn_apply_kernel: {loads requested, records summed, mean / rstd ready, table ready, stores issued} since the workgroup's start
+__device__ unsigned long long g_gna_clk[2048][6];
+extern "C" int sdmi_dbg_read_gna(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gna_clk), (size_t)n * 48) == hipSuccess ? 0 : -5;
+}
+#define GNA_STAMP(i) do { if (tid == 0) gna_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GNA_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ void load8(const void* base, int is_f32, size_t elem_off, float (&v)[8]) {
@@ -100,6 +112,10 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
   float* const t_b = gna_tab + 2 * C;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
+#ifdef SDMI_GNA_PROBE
+  unsigned long long gna_t[6] = {0, 0, 0, 0, 0, 0};
+  GNA_STAMP(0);
+#endif
   // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, p.P);
@@ -134,6 +150,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     gm[k] = c < C ? p.gamma[c] : 0.f;
     bt[k] = c < C ? p.beta[c] : 0.f;
   }
+  GNA_STAMP(1);
   const int g = tid & 31, sl = tid >> 5;
   if (p.acc0 != nullptr) {
     // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 16)
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     s_red[sl][g][0] = s;
     s_red[sl][g][1] = q;
   }
+  GNA_STAMP(2);
   __syncthreads();
   if (tid < 32) {
     // Variance as E[x^2] - E[x]^2 from fixed-order partial sums.  The cancellation costs eps * (mean/sigma)^2 relative
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     s_rstd[tid] = rsqrtf((float)var + p.eps);
   }
   __syncthreads();
+  GNA_STAMP(3);
   {
     const unsigned magic = ((1u << 20) + cpg - 1) / cpg;      // c / cpg == (c * magic) >> 20 for c < 2560, cpg <= 80
 #pragma unroll
@@ -219,6 +238,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     }
   }
   __syncthreads();
+  GNA_STAMP(4);
 #pragma unroll
   for (int k = 0; k < IT; ++k) {               // phase B: normalise (+SiLU), convert, store
     if (!ok[k]) continue;
@@ -243,6 +263,12 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
       *(f32x4*)(yp + 4) = f32x4{yf[4], yf[5], yf[6], yf[7]};
     }
   }
+#ifdef SDMI_GNA_PROBE
+  GNA_STAMP(5);
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tid == 0 && bid < 2048)
+    for (int i = 0; i < 6; ++i) g_gna_clk[bid][i] = i ? gna_t[i] - gna_t[0] : gna_t[0];
+#endif
 }
 
 // Single-launch GroupNorm for small feature maps: one 512-thread block per (group, image) keeps its whole
