@@ -95,8 +95,12 @@ __global__ __launch_bounds__(320) void gn_stats_kernel(GnArgs p, int PY, int pix
 // 512 threads x 2 items, not 256 x 4 (round 4): with the records and the gamma / beta prefetch the 256-thread form needed 189
 // registers per lane -- two workgroups per CU, two rounds of workgroups on the 64x64 maps; this one stays under 128 at 16
 // statistics loads in flight per thread.
-constexpr int GNA_NT = 512, GNA_IT = 2, GNA_SH = GNA_NT / 32;      // threads, items per thread, shares per group
+// Items (8-channel chunks) per thread: 2, or 4 when two would need more workgroups than the chip holds at once (this kernel runs two
+// 512-thread workgroups per CU: 512 slots): the concat GroupNorms of the 64x64 level were 684 workgroups = two rounds, each with
+// its own statistics chain (20 us where the one-source form of half the size took 9; round 5).
+constexpr int GNA_NT = 512, GNA_SH = GNA_NT / 32;      // threads, shares per group
 constexpr int GNA_MAXC = 2560, GNA_NCH = GNA_MAXC / GNA_NT;        // channels (launcher: C / 8 <= 320); table channels per thread
+template <int GNA_IT>
 __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_per_block) {
   sdmi_kernarg_warm<sizeof(GnArgs) + 4>();     // one miss latency for the argument block instead of one per line the compiler reaches for (common.h)
   __shared__ double s_red[GNA_SH][32][2];
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
   // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, p.P);
-  const int items = (p1 - p0) * C8;           // <= 1024 by construction (launcher): <= 2 per thread
+  const int items = (p1 - p0) * C8;           // <= GNA_IT * 512 by construction (launcher)
   constexpr int IT = GNA_IT;
   float v[IT][8];
   int px_[IT], c_[IT];
@@ -161,12 +165,18 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 16, ...
     constexpr int MAXR = 12;                            // in flight at once: 4096 records / 32 groups / 16 shares = 8 per source; a concat of a 128-row-block source and a 64-row-block one has 12; the loop below takes what is beyond
     f32x4 rv[MAXR];
+    // pair f = sl + 16 k -> (record row t, atom r of the group) incrementally: ONE division per thread instead of one per record
+    // (twelve run-time divisions sat in front of the record loads: 1.5 us of the launch by the in-kernel stamps)
+    const int dt = GNA_SH / apg, dr = GNA_SH - dt * apg;
+    int t_i = sl / apg, r_i = sl - t_i * apg;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int f = sl + GNA_SH * k;
       rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int t = t_i, a = g * apg + r_i;               // atom index in concat channel space
+      t_i += dt; r_i += dr;
+      if (r_i >= apg) { r_i -= apg; ++t_i; }
       if (f < npair) {
-        const int t = f / apg, a = g * apg + (f - t * apg);             // atom index in concat channel space
         const bool second = a >= na0;
         const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
         if (t < T) {
@@ -496,15 +506,20 @@ int sdmi_gn_launches(const GnArgs& a) {
   const long quads = ((long)a.P * (cpg / 4) + GNF_NT - 1) / GNF_NT;
   return (cpg % 4 == 0 && cpg <= 128 && a.C0 % 4 == 0 && a.P <= max_px && quads <= 12) ? 1 : 2;
 }
-// diagnostic knob (A/B only): extra dynamic LDS per gn_apply workgroup caps the workgroups per CU
-static int gna_lds_pad() {
-  static const int pad = getenv("SDMI_GNA_LDS_PAD") ? atoi(getenv("SDMI_GNA_LDS_PAD")) : 0;
-  static bool attr = false;
-  if (pad > 0 && !attr) {
-    if (hipFuncSetAttribute((const void*)gn_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) fprintf(stderr, "gn_apply: LDS attribute refused\n");
-    attr = true;
+// ~1024 items (8-channel chunks) per block, 2048 when that keeps the launch inside one round of workgroups (two per CU)
+static void launch_gn_apply(const GnArgs& a, int C8, hipStream_t st) {
+  const int C = C8 * 8;
+  static const int force_it = getenv("SDMI_GNA_IT") ? atoi(getenv("SDMI_GNA_IT")) : 0;      // A/B only: 2 or 4
+  int ppb2 = (GNA_NT * 2) / C8;
+  if (ppb2 < 1) ppb2 = 1;
+  const long blocks2 = (long)((a.P + ppb2 - 1) / ppb2) * a.B;
+  const bool four = force_it ? force_it == 4 : (blocks2 > 512 && 4 * GNA_NT / C8 >= 2);
+  if (four) {
+    const int ppb = (GNA_NT * 4) / C8;
+    hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((a.P + ppb - 1) / ppb, a.B), dim3(GNA_NT), 3 * C * sizeof(float), st, a, ppb);
+  } else {
+    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3((a.P + ppb2 - 1) / ppb2, a.B), dim3(GNA_NT), 3 * C * sizeof(float), st, a, ppb2);
   }
-  return pad;
 }
 
 int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
@@ -521,9 +536,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
                      a.accT0 > 0 && (a.accP0 == 1 || a.accP0 == 2) && (a.C1 == 0 || (a.accT1 > 0 && (a.accP1 == 1 || a.accP1 == 2))),
                  "groupnorm: producer statistics need atoms that tile every group and both concat sources, T > 0 and parts 1 or 2");
     const int C8a = C / 8;
-    int ppb = (256 * 4) / C8a;
-    if (ppb < 1) ppb = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((a.P + ppb - 1) / ppb, a.B), dim3(GNA_NT), 3 * C * sizeof(float) + gna_lds_pad(), st, a, ppb);
+    launch_gn_apply(a, C8a, st);
     SDMI_CHECK_HIP(hipGetLastError());
     return SDMI_OK;
   }
@@ -549,10 +562,7 @@ int sdmi_launch_groupnorm(const GnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(C8 * PY), 0, st, a, PY, ppc);
   SDMI_CHECK_HIP(hipGetLastError());
   // apply: ~1024 items (8-channel chunks) per block = 4 per thread
-  int ppb = (256 * 4) / C8;
-  if (ppb < 1) ppb = 1;
-  const int nblk = (a.P + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, a.B), dim3(GNA_NT), 3 * C * sizeof(float) + gna_lds_pad(), st, a, ppb);
+  launch_gn_apply(a, C8, st);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
