@@ -120,50 +120,7 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
   unsigned long long gna_t[6] = {0, 0, 0, 0, 0, 0};
   GNA_STAMP(0);
 #endif
-  // The statistics' inputs are requested FIRST (round 5: the records' reduction, not the activations' arrival, was what the
-  // normalisation waited for -- in-kernel stamps, tools/gna_clk_probe.py), the activations (cold, from the producer kernel's XCDs)
-  // and gamma / beta right behind them; then the records are added up while the activations fly.
-  const int g = tid & 31, sl = tid >> 5;
-  constexpr int MAXR = 12;                            // records in flight per thread: 4096 records / 32 groups / 16 shares = 8 per source; a concat of a 128-row-block source and a 64-row-block one has 12; a loop takes what is beyond
-  f32x4 rv[MAXR];
-  const bool from_records = p.acc0 != nullptr;
-  // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 16)
-  // adds up its share of the group's records -- apg atoms x T record rows (x parts), per concat source -- all loads in flight
-  // at once, then the shares meet in LDS exactly as the chunk partials of gn_stats_kernel do.  One pass, no statistics launch.
-  const int apg = from_records ? cpg / p.atom : 1, na0 = from_records ? p.C0 / p.atom : 0;
-  const int npair = from_records ? apg * max(p.accT0, p.accT1) : 0;      // (atom of the group, record row) pairs; this thread: sl, sl + 16, ...
-  if (from_records) {
-    // pair f = sl + 16 k -> (record row t, atom r of the group) incrementally: ONE division per thread instead of one per record
-    const int dt = GNA_SH / apg, dr2 = GNA_SH - dt * apg;
-    int t_i = sl / apg, r_i = sl - t_i * apg;
-#pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      const int f = sl + GNA_SH * k;
-      rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int t = t_i, a = g * apg + r_i;               // atom index in concat channel space
-      t_i += dt; r_i += dr2;
-      if (r_i >= apg) { r_i -= apg; ++t_i; }
-      if (f < npair) {
-        const bool second = a >= na0;
-        const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
-        if (t < T) {
-          const float* r = (second ? p.acc1 : p.acc0) + ((size_t)(n * T + t) * (second ? p.C1 / p.atom : na0) + (second ? a - na0 : a)) * parts * 2;
-          if (parts == 2) rv[k] = *(const f32x4*)r;
-          else { const f32x2 u = *(const f32x2*)r; rv[k][0] = u[0]; rv[k][1] = u[1]; }
-        }
-      }
-    }
-  } else {
-    // (statistics: the chunk partials of gn_stats_kernel; nchunk <= 128 -> at most 8 chunks per share, one latency round)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int ch = sl + GNA_SH * k;
-      const f32x2 u = ch < p.nchunk ? *(const f32x2*)(p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
-      rv[k] = f32x4{u[0], u[1], 0.f, 0.f};
-    }
-#pragma unroll
-    for (int k = 8; k < MAXR; ++k) rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  // phase A FIRST: the activation loads (cold, from the producer kernel's XCDs) fly while the statistics are reduced
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, p.P);
   const int items = (p1 - p0) * C8;           // <= GNA_IT * 512 by construction (launcher)
@@ -198,8 +155,37 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     bt[k] = c < C ? p.beta[c] : 0.f;
   }
   GNA_STAMP(1);
-  {
-    // fp64 above the per-record level (the variance is E[x^2] - E[x]^2, see below); fixed order
+  const int g = tid & 31, sl = tid >> 5;
+  if (p.acc0 != nullptr) {
+    // statistics the producers left behind (GnRec, common.h; sd/diffusion.py:173,199,294,733): thread (group g, share sl of 16)
+    // adds up its share of the group's records -- apg atoms x T record rows (x parts), per concat source -- all loads in flight
+    // at once, then the shares meet in LDS exactly as the chunk partials below do.  One pass, no statistics launch.
+    const int apg = cpg / p.atom, na0 = p.C0 / p.atom;
+    const int Tmax = max(p.accT0, p.accT1);
+    const int npair = apg * Tmax;                       // (atom of the group, record row) pairs; this thread: sl, sl + 16, ...
+    constexpr int MAXR = 12;                            // in flight at once: 4096 records / 32 groups / 16 shares = 8 per source; a concat of a 128-row-block source and a 64-row-block one has 12; the loop below takes what is beyond
+    f32x4 rv[MAXR];
+    // pair f = sl + 16 k -> (record row t, atom r of the group) incrementally: ONE division per thread instead of one per record
+    // (twelve run-time divisions sat in front of the record loads: 1.5 us of the launch by the in-kernel stamps)
+    const int dt = GNA_SH / apg, dr = GNA_SH - dt * apg;
+    int t_i = sl / apg, r_i = sl - t_i * apg;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int f = sl + GNA_SH * k;
+      rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int t = t_i, a = g * apg + r_i;               // atom index in concat channel space
+      t_i += dt; r_i += dr;
+      if (r_i >= apg) { r_i -= apg; ++t_i; }
+      if (f < npair) {
+        const bool second = a >= na0;
+        const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
+        if (t < T) {
+          const float* r = (second ? p.acc1 : p.acc0) + ((size_t)(n * T + t) * (second ? p.C1 / p.atom : na0) + (second ? a - na0 : a)) * parts * 2;
+          if (parts == 2) rv[k] = *(const f32x4*)r;
+          else { const f32x2 u = *(const f32x2*)r; rv[k][0] = u[0]; rv[k][1] = u[1]; }
+        }
+      }
+    }
     double s = 0.0, q = 0.0;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) { s += (double)rv[k][0] + (double)rv[k][2]; q += (double)rv[k][1] + (double)rv[k][3]; }
@@ -213,6 +199,20 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
         if (parts == 2) { s += (double)r[2]; q += (double)r[3]; }
       }
     }
+    s_red[sl][g][0] = s;
+    s_red[sl][g][1] = q;
+  } else {
+    // (statistics: the chunk partials of gn_stats_kernel)
+    double s = 0.0, q = 0.0;
+    // nchunk <= 128 -> at most 8 chunks per share: all loads issued at once (one latency round)
+    f32x2 pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ch = sl + GNA_SH * k;
+      pv[k] = ch < p.nchunk ? *(const f32x2*)(p.partial + (((size_t)n * p.nchunk + ch) * 32 + g) * 2) : f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += (double)pv[k][0]; q += (double)pv[k][1]; }
     s_red[sl][g][0] = s;
     s_red[sl][g][1] = q;
   }
