@@ -169,12 +169,6 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
     // (twelve run-time divisions sat in front of the record loads: 1.5 us of the launch by the in-kernel stamps)
     const int dt = GNA_SH / apg, dr = GNA_SH - dt * apg;
     int t_i = sl / apg, r_i = sl - t_i * apg;
-    // per source: first record of this image and the stride of a record row, in floats (wave-uniform: scalar arithmetic); per
-    // record one compare, three selects and a multiply-add are left on the vector unit
-    const int na1 = p.C1 / p.atom;
-    const float* const b0 = p.acc0 + (size_t)n * p.accT0 * na0 * p.accP0 * 2;
-    const float* const b1 = p.acc1 ? p.acc1 + (size_t)n * p.accT1 * na1 * p.accP1 * 2 : p.acc0;
-    const int rs0 = na0 * p.accP0 * 2, rs1 = na1 * p.accP1 * 2, as0 = p.accP0 * 2, as1 = p.accP1 * 2;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int f = sl + GNA_SH * k;
@@ -182,12 +176,14 @@ __global__ __launch_bounds__(GNA_NT, 4) void gn_apply_kernel(GnArgs p, int pix_p
       const int t = t_i, a = g * apg + r_i;               // atom index in concat channel space
       t_i += dt; r_i += dr;
       if (r_i >= apg) { r_i -= apg; ++t_i; }
-      const bool second = a >= na0;
-      const int T = second ? p.accT1 : p.accT0;
-      if (f < npair && t < T) {
-        const float* r = (second ? b1 : b0) + t * (second ? rs1 : rs0) + (second ? a - na0 : a) * (second ? as1 : as0);
-        if ((second ? p.accP1 : p.accP0) == 2) rv[k] = *(const f32x4*)r;
-        else { const f32x2 u = *(const f32x2*)r; rv[k][0] = u[0]; rv[k][1] = u[1]; }
+      if (f < npair) {
+        const bool second = a >= na0;
+        const int T = second ? p.accT1 : p.accT0, parts = second ? p.accP1 : p.accP0;
+        if (t < T) {
+          const float* r = (second ? p.acc1 : p.acc0) + ((size_t)(n * T + t) * (second ? p.C1 / p.atom : na0) + (second ? a - na0 : a)) * parts * 2;
+          if (parts == 2) rv[k] = *(const f32x4*)r;
+          else { const f32x2 u = *(const f32x2*)r; rv[k][0] = u[0]; rv[k][1] = u[1]; }
+        }
       }
     }
     double s = 0.0, q = 0.0;
