@@ -286,7 +286,10 @@ def cmd_compare(oldp, newp, tol=0.05, allow=None, floor_us=1.0, use_drift=True):
             rows.append(f"  GONE     {k:70s} x{o[0]:3d} {o[1]:8.1f} us")
             continue
         d = n[1] - o[1]
-        slow = d > tol * o[1] and d > floor_us and n[1] / max(n[0], 1) > (1 + tol) * drift * o[1] / max(o[0], 1)
+        # slower per launch by more than tol beyond the drift AND by more than floor_us per launch (launches of 5 - 20 us jitter by
+        # 0.5 - 1 us from box to box and run to run: five profiles of one binary, round 5)
+        per_o, per_n = o[1] / max(o[0], 1), n[1] / max(n[0], 1)
+        slow = per_n > (1 + tol) * drift * per_o and per_n - drift * per_o > floor_us
         why = next((w for p, w in reasons if p in k), None) if slow else None
         tag = "ok"
         if slow:
