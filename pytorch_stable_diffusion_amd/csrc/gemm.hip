@@ -1575,7 +1575,6 @@ __global__ __launch_bounds__(GN ? C::NT + 64 * C::NW : C::NT) void conv3_halo_ke
 
 // out = sum_z slab[z] + bias + res  (same epilogue semantics as the fused path): one item = 8 columns n .. n+7 of slab row ms.
 // Returns true with the values the GroupNorm of this tensor will read in x (the non-transposed path only).
-template <int kFinZB>      // slabs whose loads are in flight together
 __device__ __forceinline__ bool finalize_item(const GemmArgs& p, int ms, int n, size_t MN, float (&x)[8]) {
   {
     const int m = out_row(p, ms);                               // output row (phase2 scatter; identity otherwise)
@@ -1599,13 +1598,12 @@ __device__ __forceinline__ bool finalize_item(const GemmArgs& p, int ms, int n, 
     // bias with the first slab loads (it was read element by element after the last slab: one more exposed latency)
     f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) { bv0 = *(const f32x4*)(p.bias + n); bv1 = *(const f32x4*)(p.bias + n + 4); }
-    // EIGHT slabs' loads in flight at a time (a load-add-load-add chain paid one memory latency per slab; four at a time -- rounds
-    // 3 and 4 -- still paid two for the split-6 combines that most of the 16x16 / 8x8 convs end in); the additions stay in slab
-    // order, so the result is bit-identical
-    for (int z0 = 0; z0 < p.ksplit; z0 += kFinZB) {
-      f32x4 s0[kFinZB], s1[kFinZB];
+    // four slabs' loads in flight at a time (a load-add-load-add chain paid one memory latency per slab); the
+    // additions stay in slab order, so the result is bit-identical
+    for (int z0 = 0; z0 < p.ksplit; z0 += 4) {
+      f32x4 s0[4], s1[4];
 #pragma unroll
-      for (int j = 0; j < kFinZB; ++j) {
+      for (int j = 0; j < 4; ++j) {
         if (z0 + j < p.ksplit) {
           const float* sp = p.slab + (size_t)(z0 + j) * MN + (size_t)ms * p.N + n;
           s0[j] = *(const f32x4*)sp;
@@ -1613,7 +1611,7 @@ __device__ __forceinline__ bool finalize_item(const GemmArgs& p, int ms, int n, 
         }
       }
 #pragma unroll
-      for (int j = 0; j < kFinZB; ++j) {
+      for (int j = 0; j < 4; ++j) {
         if (z0 + j < p.ksplit) {
           if (z0 + j < n_fold) {
 #pragma unroll
@@ -1681,7 +1679,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total8; idx += gridDim.x * 256u) {
     const unsigned mq = idx / n8;
     float x[8];
-    (void)finalize_item<8>(p, (int)mq, (int)(idx - mq * n8) * 8, MN, x);
+    (void)finalize_item(p, (int)mq, (int)(idx - mq * n8) * 8, MN, x);
   }
 }
 
@@ -1709,7 +1707,7 @@ __global__ __launch_bounds__(kFinNT) void splitk_finalize_gacc_kernel(GemmArgs p
   for (int i = 0; i < NI; ++i) {
     const int ms = row_base + r0 + i * rpp;      // < M: rows_wg divides the rows of an image (launcher)
     float x[8];
-    if (finalize_item<(NI == 1 ? 8 : 4)>(p, ms, n, MN, x)) gth.add(x, split);      // (NI items are unrolled: eight slabs each would spill)
+    if (finalize_item(p, ms, n, MN, x)) gth.add(x, split);
   }
   *(f32x4*)(s_g + tid * 4) = gth.parts(split);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (not __syncthreads(): its vmcnt(0) would wait for the output stores to retire)

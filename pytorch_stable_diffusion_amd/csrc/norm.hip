@@ -314,7 +314,7 @@ __global__ __launch_bounds__(GNF_NT) void gn_fused_kernel(GnArgs p) {
     // MAXQ (x ZB) 16-byte loads per thread outstanding instead of one slot's four; the additions per element stay in slab
     // order, so the sum is bit-identical to splitk_finalize's.
     const size_t MN = (size_t)p.B * p.P * C;
-    constexpr int ZB = MAXQ <= 4 ? 8 : 1;           // (round 5: eight, so that a split-6 producer's slabs arrive in ONE latency round, a split-12's in two)
+    constexpr int ZB = MAXQ <= 4 ? 4 : 1;
     size_t off[MAXQ];
     bool ok[MAXQ];
 #pragma unroll
