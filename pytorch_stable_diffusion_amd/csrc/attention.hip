@@ -396,12 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
       }
   };
 
-  // Two tiles per key stream (cross-attention's 77 keys, the 16x16 level's 256): BOTH are requested here and the loop neither
-  // stages nor waits nor meets at a barrier again (round 5: the second tile's request used to follow the first's arrival -- two cold
-  // latencies in a launch whose whole life is ~10 us).
-  const bool both_now = NB == 2 && ntiles == 2 && !(SDMI_ATTN_ABLATE & 24);
   stage(0);
-  if (both_now) stage(1);
   if (NB == 3 && ntiles > 1) {
     stage(1);
     wait_vm_upto(per_stage);              // tile 0 has landed, tile 1 may still fly
@@ -424,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
 #ifdef SDMI_ATTN_PROBE
     const unsigned long long c0 = ATTN_T();
 #endif
-    if (!(SDMI_ATTN_ABLATE & 8) && !both_now && t + NB - 1 < ntiles) stage(nxt);
+    if (!(SDMI_ATTN_ABLATE & 8) && t + NB - 1 < ntiles) stage(nxt);
 #ifdef SDMI_ATTN_PROBE
     const unsigned long long c1 = ATTN_T();
 #endif
@@ -433,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_kernel(AttnArgs
     const unsigned long long c2 = ATTN_T();
     unsigned long long c3 = c2, c4 = c2;
 #endif
-    if (!(SDMI_ATTN_ABLATE & 16) && !both_now && t + 1 < ntiles) {
+    if (!(SDMI_ATTN_ABLATE & 16) && t + 1 < ntiles) {
       // RAW for step t+1: every wave waits for ITS pieces of tile t+1, then the barrier publishes them.  NB = 3: the stage
       // issued in this step (tile t+2) stays in flight -- a plain s_barrier, not __syncthreads(), whose fence would drain it
       if (NB == 3 && t + 2 < ntiles) wait_vm_upto(per_stage);
