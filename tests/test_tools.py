@@ -40,3 +40,52 @@ def test_looser_tolerance_passes():
     old = os.path.join(ROOT, "profiles", "r03_step_by_shape.txt")
     new = os.path.join(ROOT, "profiles", "r04_step_by_shape.txt")
     assert _run(old, new, "--tol", "0.5").returncode == 0
+
+
+def _scaled_profile(src, dst, factor, only=None, add_us=0.0):
+    """copy a step_by_shape profile with every (or one) shape's time scaled / shifted"""
+    import re
+    out = []
+    for ln in open(src):
+        m = re.search(r"x\s*(\d+)\s+([0-9.]+) us\s+avg\s+([0-9.]+)", ln)
+        if m and (only is None or only in ln):
+            n, tot = int(m.group(1)), float(m.group(2))
+            tot2 = tot * factor + add_us * n
+            ln = ln[:m.start()] + f"x{n:3d} {tot2:8.1f} us  avg {tot2 / n:7.2f}" + ln[m.end():]
+        out.append(ln)
+    open(dst, "w").write("".join(out))
+
+
+def test_gate_judges_against_the_box_drift(tmp_path):
+    """Round 5: the same binary on a pool box that is 2 % slower must not read as eighty regressions -- shapes are judged against the
+    median per-launch ratio of the comparison -- while one shape that is 8 % slower on top of the drift is still named; without the
+    drift model (--no-drift) the slower box alone is enough for shapes near the threshold."""
+    base = os.path.join(ROOT, "profiles", "r05_step_by_shape.txt")
+    slow_box = tmp_path / "slow_box.txt"
+    _scaled_profile(base, slow_box, 1.02)
+    r = _run(base, str(slow_box))
+    assert r.returncode == 0 and "box drift" in r.stdout and "1.020" in r.stdout, r.stdout
+    one_bad = tmp_path / "one_bad.txt"
+    _scaled_profile(str(slow_box), one_bad, 1.08, only="halo     M= 8192 N=  320 K= 2880")
+    r = _run(base, str(one_bad))
+    assert r.returncode == 1 and "SLOWER   conv M=8192 N=320 K=2880" in r.stdout, r.stdout
+    assert r.stdout.count("SLOWER") == 1, r.stdout
+    # a 4 % slower box, still inside the tolerance with the drift taken out (clamped at 3 %): only --no-drift names nothing either,
+    # but 6 % does without the model and does not with it up to the clamp
+    six = tmp_path / "six.txt"
+    _scaled_profile(base, six, 1.06)
+    assert _run(base, str(six), "--no-drift").returncode == 1
+    r = _run(base, str(six))
+    assert r.returncode == 1 and "whole step" in r.stdout, r.stdout       # a uniform 6 % is a regression of the step itself
+
+
+def test_gate_ignores_sub_microsecond_jitter(tmp_path):
+    """a 5 us launch that measures 0.6 us slower (12 %) is box-to-box jitter, not a regression: the per-launch floor is 1 us"""
+    base = os.path.join(ROOT, "profiles", "r05_step_by_shape.txt")
+    jit = tmp_path / "jitter.txt"
+    _scaled_profile(base, jit, 1.0, only="gn_fused C=1280 P=64", add_us=0.6)
+    assert _run(base, str(jit)).returncode == 0
+    bad = tmp_path / "bad.txt"
+    _scaled_profile(base, bad, 1.0, only="gn_fused C=1280 P=64", add_us=1.5)
+    r = _run(base, str(bad))
+    assert r.returncode == 1 and "gn_fused C=1280 P=64" in r.stdout, r.stdout
