@@ -240,7 +240,7 @@ def run_prompts(prompts: Sequence[str], models: Dict[str, object], tokenizer, de
 
     Both together: ``streams_per_gpu`` lanes, each carrying groups of ``batch_per_gpu`` prompts -- the batched chains amortise
     the weight traffic and the launch-bound levels, the lanes fill what latency is left (measured on one MI355X, DESIGN.md 6:
-    2 lanes x 6 prompts 496-523 UNet steps/s in aggregate beside 252-262 for one chain, one batched chain of 8 457-470).  The
+    2 lanes x 6 prompts 520-535 UNet steps/s in aggregate beside 254-264 for one chain, one batched chain of 8 474-486; round 5).  The
     activation arena of each lane grows by itself for the batch it is given (csrc/engine.h ensure_arena): no environment knob
     is needed for groups beyond four prompts.
 
